@@ -1,0 +1,214 @@
+// fasn_api.hip — the C ABI of libfasn (include/fasn.h): argument validation, parameter packing, dispatch.
+// No allocation, no synchronisation (the fasn_time_* helpers excepted: they exist to time launches).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include "fasn.h"
+#include "fasn_launch.h"
+#include "fasn_bwd_launch.h"
+
+using namespace fasn;
+
+namespace {
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// rows must stay 16-byte aligned: base pointer and every non-feature stride (in 2-byte elements) % 8
+int check_view(const fasn_view4& v, bool required) {
+    if (v.ptr == nullptr) return required ? FASN_EINVAL : FASN_OK;
+    if (v.stride[3] != 1) return FASN_ESTRIDE;
+    if (!aligned16(v.ptr)) return FASN_EALIGN;
+    for (int i = 0; i < 3; ++i)
+        if (v.stride[i] % 8 != 0) return FASN_EALIGN;
+    return FASN_OK;
+}
+
+int internal_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FASN_FWD_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
+    if (a == nullptr) return FASN_EINVAL;
+    if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0 || a->D <= 0 || a->Dv <= 0) return FASN_EINVAL;
+    if (a->dtype != FASN_DTYPE_F16 && a->dtype != FASN_DTYPE_BF16) return FASN_EDTYPE;
+    if (!fasn_supported(a->dtype, a->D, a->Dv)) return FASN_EHEADDIM;
+    if (a->dropout_p != 0.f) return FASN_EUNSUPPORTED;
+    if (!(a->softmax_n >= 0.f) || !(a->scale >= 0.f) || !isfinite(a->scale)) return FASN_EINVAL;
+    int rc;
+    if ((rc = check_view(a->q, true))) return rc;
+    if ((rc = check_view(a->k, true))) return rc;
+    if ((rc = check_view(a->v, true))) return rc;
+    if ((rc = check_view(a->o, true))) return rc;
+    if (a->bias.ptr != nullptr && a->bias_dtype != FASN_BIAS_SAME && a->bias_dtype != FASN_BIAS_F32) return FASN_EINVAL;
+
+    p.q = (const char*)a->q.ptr;
+    p.k = (const char*)a->k.ptr;
+    p.v = (const char*)a->v.ptr;
+    p.o = (char*)a->o.ptr;
+    p.lse = a->lse;
+    p.mask = (const uint8_t*)a->mask.ptr;
+    p.bias = (const char*)a->bias.ptr;
+    for (int i = 0; i < 3; ++i) {
+        p.qs[i] = a->q.stride[i];
+        p.ks[i] = a->k.stride[i];
+        p.vs[i] = a->v.stride[i];
+        p.os[i] = a->o.stride[i];
+    }
+    for (int i = 0; i < 4; ++i) {
+        p.ms[i] = a->mask.ptr ? a->mask.stride[i] : 0;
+        p.bs[i] = a->bias.ptr ? a->bias.stride[i] : 0;
+    }
+    p.B = a->B;
+    p.H = a->H;
+    p.Sq = a->Sq;
+    p.Sk = a->Sk;
+    p.nqblk = 0;
+    p.causal = a->causal ? 1 : 0;
+    p.bias_f32 = (a->bias.ptr && a->bias_dtype == FASN_BIAS_F32) ? 1 : 0;
+    p.c = a->scale * kLog2e;
+    p.n = a->softmax_n;
+
+    l.dtype = a->dtype;
+    l.D = a->D;
+    l.mode = (a->mask.ptr || a->bias.ptr) ? MODE_GENERAL : (a->causal ? MODE_CAUSAL : MODE_PLAIN);
+    l.variant = internal_variant();
+    return FASN_OK;
+}
+
+int dispatch_fwd(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    switch (l.D) {
+        case 32: return launch_fwd_d32(p, l, s);
+        case 64: return launch_fwd_d64(p, l, s);
+        case 128: return launch_fwd_d128(p, l, s);
+        default: return FASN_EHEADDIM;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fasn_abi_version(void) { return FASN_ABI_VERSION; }
+
+const char* fasn_strerror(int code) {
+    switch (code) {
+        case FASN_OK: return "ok";
+        case FASN_EINVAL: return "invalid argument (null pointer, non-positive size, negative n/scale, bad enum)";
+        case FASN_EDTYPE: return "unsupported element type (supported: fp16, bf16)";
+        case FASN_EHEADDIM: return "unsupported head dimension (supported: D == Dv in {32, 64, 128})";
+        case FASN_EALIGN: return "pointer or stride breaks the 16-byte row alignment rule";
+        case FASN_ESTRIDE: return "feature (last-dim) stride must be 1";
+        case FASN_ELAUNCH: return "kernel launch failed";
+        case FASN_EUNSUPPORTED: return "request not implemented in this build (dropout_p must be 0)";
+        case FASN_EWORKSPACE: return "workspace missing or too small";
+        default: return "unknown fasn error";
+    }
+}
+
+int fasn_supported(int32_t dtype, int32_t D, int32_t Dv) {
+    if (dtype != FASN_DTYPE_F16 && dtype != FASN_DTYPE_BF16) return 0;
+    if (D != Dv) return 0;
+    return (D == 32 || D == 64 || D == 128) ? 1 : 0;
+}
+
+int fasn_fwd(const fasn_fwd_args* args, fasn_stream_t stream) {
+    FwdParams p;
+    FwdLaunch l;
+    const int rc = build_fwd(args, p, l);
+    if (rc) return rc;
+    return dispatch_fwd(p, l, (hipStream_t)stream);
+}
+
+// internal: forward with an explicit tuning variant (used by tools/fasn_harness)
+int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant) {
+    FwdParams p;
+    FwdLaunch l;
+    const int rc = build_fwd(args, p, l);
+    if (rc) return rc;
+    l.variant = variant;
+    return dispatch_fwd(p, l, (hipStream_t)stream);
+}
+
+size_t fasn_bwd_workspace_bytes(const fasn_bwd_args* args) {
+    (void)args;
+    return 0;
+}
+
+int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
+    if (a == nullptr) return FASN_EINVAL;
+    FwdParams fp;
+    FwdLaunch l;
+    int rc = build_fwd(&a->fwd, fp, l);
+    if (rc) return rc;
+    if (a->fwd.lse == nullptr || a->delta == nullptr) return FASN_EINVAL;
+    if ((rc = check_view(a->dout, true))) return rc;
+    if ((rc = check_view(a->dq, true))) return rc;
+    if ((rc = check_view(a->dk, true))) return rc;
+    if ((rc = check_view(a->dv, true))) return rc;
+    BwdParams p;
+    p.f = fp;
+    p.dout = (const char*)a->dout.ptr;
+    p.dq = (char*)a->dq.ptr;
+    p.dk = (char*)a->dk.ptr;
+    p.dv = (char*)a->dv.ptr;
+    p.delta = a->delta;
+    p.scale = a->fwd.scale;
+    for (int i = 0; i < 3; ++i) {
+        p.dos[i] = a->dout.stride[i];
+        p.dqs[i] = a->dq.stride[i];
+        p.dks[i] = a->dk.stride[i];
+        p.dvs[i] = a->dv.stride[i];
+    }
+    return launch_bwd(p, l, (hipStream_t)stream);
+}
+
+int fasn_time_fwd(const fasn_fwd_args* args, fasn_stream_t stream, int32_t warmup, int32_t iters, float* ms_per_iter) {
+    if (ms_per_iter == nullptr || iters <= 0) return FASN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < warmup; ++i) {
+        const int rc = fasn_fwd(args, stream);
+        if (rc) return rc;
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FASN_ELAUNCH;
+    (void)hipEventRecord(e0, s);
+    int rc = 0;
+    for (int i = 0; i < iters && rc == 0; ++i) rc = fasn_fwd(args, stream);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_iter = ms / (float)iters;
+    return rc;
+}
+
+int fasn_time_bwd(const fasn_bwd_args* args, fasn_stream_t stream, int32_t warmup, int32_t iters, float* ms_per_iter) {
+    if (ms_per_iter == nullptr || iters <= 0) return FASN_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < warmup; ++i) {
+        const int rc = fasn_bwd(args, stream);
+        if (rc) return rc;
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FASN_ELAUNCH;
+    (void)hipEventRecord(e0, s);
+    int rc = 0;
+    for (int i = 0; i < iters && rc == 0; ++i) rc = fasn_bwd(args, stream);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_iter = ms / (float)iters;
+    return rc;
+}
+
+}  // extern "C"

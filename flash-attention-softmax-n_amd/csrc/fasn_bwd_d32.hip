@@ -1,0 +1,7 @@
+// D = 32 backward instantiations: <QB (dQ: 32-row blocks/wave), KB (dK/dV: 32-key blocks/wave), occupancies>
+#include "fasn_bwd_launch.h"
+namespace fasn {
+int launch_bwd_d32(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    return l.dtype == 1 ? launch_bwd_mode<bf16_tag, 32, 2, 2, 2, 2>(p, l.mode, s) : launch_bwd_mode<f16_tag, 32, 2, 2, 2, 2>(p, l.mode, s);
+}
+}  // namespace fasn

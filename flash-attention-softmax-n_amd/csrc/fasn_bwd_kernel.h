@@ -1,0 +1,564 @@
+// fasn_bwd_kernel.h — backward of attention-softmax_n by recomputation, deterministic (no atomics).
+//
+// With LSE_i = log(n + sum_j exp x_ij) saved by the forward, P_ij = exp(x_ij - LSE_i) already carries
+// the "+n" of softmax_n and the softmax backward keeps its usual form
+// (reference math: flash_attention_softmax_n/core/functional.py:15-29 differentiated; the reference's own
+// Triton backward, flash_attn_triton.py:146-235, saves an LSE WITHOUT n — not reproduced here):
+//   delta_i = dO_i . O_i
+//   dV = P^T dO          dP = dO V^T          dS = P o (dP - delta)
+//   dQ = scale * dS K    dK = scale * dS^T Q
+//
+// Three kernels:
+//   fasn_bwd_delta : delta[b,h,i]                                  (replaces _bwd_preprocess, :129-143)
+//   fasn_bwd_dq    : one workgroup per 32*QB*4 query rows, walks K/V tiles (same orientation as forward:
+//                    a lane owns a query row; S^T, dP^T, dS^T in accumulator layout feed dQ^T += K^T dS^T)
+//   fasn_bwd_dkdv  : one workgroup per 32*KB*4 keys, walks Q/dO tiles (a lane owns a key column;
+//                    S, dP, dS [q][key] feed dV^T += dO^T P and dK^T += Q^T dS)
+// Both big kernels reuse the forward's two LDS access patterns (row fragments by ds_read_b128 and
+// transposed fragments by ds_read_b64_tr_b16 on the same swizzled tile image).
+#pragma once
+#include "fasn_common.h"
+#include "fasn_fwd_kernel.h"
+
+namespace fasn {
+
+struct BwdParams {
+    FwdParams f;  // q,k,v,o,lse,mask,bias + strides + sizes; f.c = scale*log2e
+    const char* dout;
+    char* dq;
+    char* dk;
+    char* dv;
+    float* delta;
+    int64_t dos[3], dqs[3], dks[3], dvs[3];
+    float scale;
+    int nblk;  // blocks per head of the launching kernel
+};
+
+// ---------------------------------------------------------------------------------------------
+// delta[b,h,i] = sum_d O[i][d] * dO[i][d]      (D/8 lanes per row, 16-byte loads)
+template <typename Tag, int D>
+__global__ void __launch_bounds__(256) fasn_bwd_delta_kernel(const BwdParams p) {
+    using E = ET<Tag>;
+    constexpr int LPR = D / 8;        // lanes per row
+    constexpr int RPB = 256 / LPR;    // rows per block
+    const int tid = threadIdx.x;
+    const int sub = tid % LPR;
+    const int64_t rows = (int64_t)p.f.B * p.f.H * p.f.Sq;
+    const int64_t gr = (int64_t)blockIdx.x * RPB + tid / LPR;
+    float acc = 0.f;
+    if (gr < rows) {
+        const int i = (int)(gr % p.f.Sq);
+        const int bh = (int)(gr / p.f.Sq);
+        const int b = bh / p.f.H, h = bh % p.f.H;
+        const char* op = p.f.o + (b * p.f.os[0] + h * p.f.os[1] + (int64_t)i * p.f.os[2]) * 2 + sub * 16;
+        const char* dp = p.dout + (b * p.dos[0] + h * p.dos[1] + (int64_t)i * p.dos[2]) * 2 + sub * 16;
+        u32x4 a = gload16(op), d = gload16(dp);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            acc += E::to_f32((uint16_t)(a[w] & 0xffff)) * E::to_f32((uint16_t)(d[w] & 0xffff));
+            acc += E::to_f32((uint16_t)(a[w] >> 16)) * E::to_f32((uint16_t)(d[w] >> 16));
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) acc += __shfl_xor(acc, o);
+    if (gr < rows && sub == 0) p.delta[gr] = acc;
+}
+
+// shared helper: stage a [64][D] tile (rows row0..row0+63 of a [S][D] matrix) into registers / LDS
+template <int D, int NLD>
+FASN_DEV void tile_gload(u32x4 (&st)[NLD], const char* base, int64_t row_stride, int row0, int nrows_total, int tid) {
+    constexpr int CPR = D / 8;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int ci = tid + i * 256;
+        const int row = ci / CPR, ch = ci % CPR;
+        const int gr = row0 + row;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        if (gr < nrows_total) z = gload16(base + (int64_t)gr * row_stride * 2 + ch * 16);
+        st[i] = z;
+    }
+}
+template <int D, int NLD>
+FASN_DEV void tile_lstore(const u32x4 (&st)[NLD], char* tile, int tid) {
+    constexpr int CPR = D / 8;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int ci = tid + i * 256;
+        const int row = ci / CPR, ch = ci % CPR;
+        *LDS_PTR(u32x4, tile + tile_off<D>(row, ch)) = st[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dQ: workgroup = 4 waves x QB x 32 query rows, loop over 64-key tiles.
+template <typename Tag, int D, int QB, int MODE, int OCC>
+__global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams bp) {
+    using E = ET<Tag>;
+    using vec8 = typename E::vec8;
+    const FwdParams& p = bp.f;
+    constexpr int BM = 4 * QB * 32;
+    constexpr int TILEB = KT * D * 2;
+    constexpr int KS = D / 16;
+    constexpr int DB = D / 32;
+    constexpr int NLD = (KT * (D / 8)) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsK = smem;
+    char* const ldsV = smem + 2 * TILEB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+
+    int bh, qi;
+    block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
+    const bool causal = (MODE == MODE_CAUSAL) || (MODE == MODE_GENERAL && p.causal);
+    const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qblk * BM;
+    const int qw0 = q0 + wave * (QB * 32);
+    const int coff = p.Sk - p.Sq;
+
+    const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
+    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
+    const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2;
+
+    int ntiles = (p.Sk + KT - 1) / KT;
+    if (causal) {
+        const int kmax = min(q0 + BM, p.Sq) - 1 + coff;
+        ntiles = min(ntiles, kmax < 0 ? 0 : (kmax / KT + 1));
+    }
+
+    vec8 qf[QB][KS], dof[QB][KS];
+    float lse2[QB], dlt[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int row = qw0 + qb * 32 + l31;
+        const bool ok = row < p.Sq;
+        const char* rq = qbase + (int64_t)row * p.qs[2] * 2 + hi * 16;
+        const char* rd = dobase + (int64_t)row * bp.dos[2] * 2 + hi * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 a = {0u, 0u, 0u, 0u}, d = {0u, 0u, 0u, 0u};
+            if (ok) {
+                a = gload16(rq + s * 32);
+                d = gload16(rd + s * 32);
+            }
+            __builtin_memcpy(&qf[qb][s], &a, 16);
+            __builtin_memcpy(&dof[qb][s], &d, 16);
+        }
+        float l = ok ? p.lse[(int64_t)bh * p.Sq + row] : 0.f;
+        lse2[qb] = (l == -INFINITY) ? INFINITY : l * kLog2e;
+        dlt[qb] = ok ? bp.delta[(int64_t)bh * p.Sq + row] : 0.f;
+    }
+
+    f32x16 dqacc[QB][DB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqacc[qb][d][r] = 0.f;
+
+    u32x4 stK[NLD], stV[NLD];
+    if (ntiles > 0) {
+        tile_gload<D, NLD>(stK, kbase, p.ks[2], 0, p.Sk, tid);
+        tile_gload<D, NLD>(stV, vbase, p.vs[2], 0, p.Sk, tid);
+        tile_lstore<D, NLD>(stK, ldsK, tid);
+        tile_lstore<D, NLD>(stV, ldsV, tid);
+    }
+    __syncthreads();
+
+    const int wave_first_vis = qw0 + coff;
+    const int wave_last_vis = qw0 + QB * 32 - 1 + coff;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const int k0 = t * KT;
+        if (t + 1 < ntiles) {
+            tile_gload<D, NLD>(stK, kbase, p.ks[2], k0 + KT, p.Sk, tid);
+            tile_gload<D, NLD>(stV, vbase, p.vs[2], k0 + KT, p.Sk, tid);
+        }
+        bool skip = false, need_mask = false;
+        if (causal) {
+            skip = k0 > wave_last_vis;
+            need_mask = (k0 + KT - 1) > wave_first_vis;
+        }
+        if (k0 + KT > p.Sk) need_mask = true;
+        if (MODE == MODE_GENERAL) need_mask = true;
+
+        if (!skip) {
+            const char* tK = ldsK + buf * TILEB;
+            const char* tV = ldsV + buf * TILEB;
+            f32x16 sacc[QB][2], pacc[QB][2];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        sacc[qb][kb][r] = 0.f;
+                        pacc[qb][kb][r] = 0.f;
+                    }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
+                    vec8 vf = lds_read_rowfrag<E, D>(tV, kb * 32 + l31, s, hi);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
+                        pacc[qb][kb] = E::mfma(vf, dof[qb][s], pacc[qb][kb]);
+                    }
+                }
+
+            vec8 dsf[QB][2][2];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const int row = qw0 + qb * 32 + l31;
+                const int vis = causal ? (row + coff) : 0x7fffffff;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float y = sacc[qb][kb][r] * p.c;
+                        bool show = true;
+                        if (need_mask) {
+                            const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            show = (key < p.Sk) && (key <= vis);
+                            if (MODE == MODE_GENERAL) {
+                                const bool inb = show && (row < p.Sq);
+                                if (p.bias != nullptr && inb) {
+                                    const int64_t bo = b * p.bs[0] + h * p.bs[1] + (int64_t)row * p.bs[2] + (int64_t)key * p.bs[3];
+                                    float bv;
+                                    if (p.bias_f32) bv = reinterpret_cast<const float*>(p.bias)[bo];
+                                    else bv = E::to_f32(reinterpret_cast<const uint16_t*>(p.bias)[bo]);
+                                    y = __builtin_fmaf(bv, kLog2e, y);
+                                }
+                                if (p.mask != nullptr && inb) {
+                                    const int64_t mo = b * p.ms[0] + h * p.ms[1] + (int64_t)row * p.ms[2] + (int64_t)key * p.ms[3];
+                                    show = p.mask[mo] != 0;
+                                }
+                            }
+                        }
+                        float pv = fast_exp2(y - lse2[qb]);
+                        pv = show ? pv : 0.f;
+                        sacc[qb][kb][r] = pv * (pacc[qb][kb][r] - dlt[qb]);
+                    }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        f32x8 x;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = sacc[qb][kb][8 * t2 + e];
+                        dsf[qb][kb][t2] = E::cvt8(x);
+                    }
+            }
+            // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) {
+                        vec8 ktf = lds_read_trfrag<E, D>(tK, kb * 32 + 16 * t2, d, lane);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) dqacc[qb][d] = E::mfma(ktf, dsf[qb][kb][t2], dqacc[qb][d]);
+                    }
+        }
+        if (t + 1 < ntiles) {
+            tile_lstore<D, NLD>(stK, ldsK + (buf ^ 1) * TILEB, tid);
+            tile_lstore<D, NLD>(stV, ldsV + (buf ^ 1) * TILEB, tid);
+        }
+        __syncthreads();
+    }
+
+    char* dqbase = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1]) * 2;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int row = qw0 + qb * 32 + l31;
+        if (row < p.Sq) {
+            char* rp = dqbase + (int64_t)row * bp.dqs[2] * 2;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = dqacc[qb][d][4 * g + e] * bp.scale;
+                    typename E::vec4 y = E::cvt4(x);
+                    u32x2 raw;
+                    __builtin_memcpy(&raw, &y, 8);
+                    gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dK, dV: workgroup = 4 waves x KB x 32 keys, loop over 64-row Q/dO tiles.
+constexpr int QT = 64;  // query rows per tile
+
+template <typename Tag, int D, int KB, int MODE, int OCC>
+__global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams bp) {
+    using E = ET<Tag>;
+    using vec8 = typename E::vec8;
+    const FwdParams& p = bp.f;
+    constexpr int BN = 4 * KB * 32;
+    constexpr int TILEB = QT * D * 2;
+    constexpr int KS = D / 16;
+    constexpr int DB = D / 32;
+    constexpr int NLD = (QT * (D / 8)) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsQ = smem;                    // [2][TILEB]
+    char* const ldsDO = smem + 2 * TILEB;       // [2][TILEB]
+    float* const ldsLse = reinterpret_cast<float*>(smem + 4 * TILEB);  // [2][QT] lse*log2e
+    float* const ldsDlt = ldsLse + 2 * QT;                             // [2][QT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+
+    int bh, kblk;
+    block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
+    const bool causal = (MODE == MODE_CAUSAL) || (MODE == MODE_GENERAL && p.causal);
+    const int b = bh / p.H, h = bh % p.H;
+    const int kw0 = kblk * BN + wave * (KB * 32);  // first key of this wave
+    const int coff = p.Sk - p.Sq;
+
+    const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
+    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
+    const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2;
+    const float* lsebase = p.lse + (int64_t)bh * p.Sq;
+    const float* dltbase = bp.delta + (int64_t)bh * p.Sq;
+
+    // query tiles that can see this key block: rows i with i + coff >= first key
+    const int ntq = (p.Sq + QT - 1) / QT;
+    int tq0 = 0;
+    if (causal) {
+        const int first_row = kblk * BN - coff;
+        tq0 = first_row <= 0 ? 0 : first_row / QT;
+    }
+
+    // K / V fragments of this wave's keys (B operand: col = key = lane&31, k = 8 contiguous features)
+    vec8 kf[KB][KS], vf[KB][KS];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int key = kw0 + kb * 32 + l31;
+        const bool ok = key < p.Sk;
+        const char* rk = kbase + (int64_t)key * p.ks[2] * 2 + hi * 16;
+        const char* rv = vbase + (int64_t)key * p.vs[2] * 2 + hi * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
+            if (ok) {
+                a = gload16(rk + s * 32);
+                c = gload16(rv + s * 32);
+            }
+            __builtin_memcpy(&kf[kb][s], &a, 16);
+            __builtin_memcpy(&vf[kb][s], &c, 16);
+        }
+    }
+
+    f32x16 dkacc[KB][DB], dvacc[KB][DB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[kb][d][r] = 0.f;
+                dvacc[kb][d][r] = 0.f;
+            }
+
+    u32x4 stQ[NLD], stD[NLD];
+    float stL = 0.f, stX = 0.f;
+    auto stats_gload = [&](int row0) {
+        if (tid < QT) {
+            const int gr = row0 + tid;
+            float l = 0.f, x = 0.f;
+            if (gr < p.Sq) {
+                l = lsebase[gr];
+                x = dltbase[gr];
+            }
+            stL = (l == -INFINITY) ? INFINITY : l * kLog2e;
+            stX = x;
+        }
+    };
+    auto stats_lstore = [&](int buf) {
+        if (tid < QT) {
+            ldsLse[buf * QT + tid] = stL;
+            ldsDlt[buf * QT + tid] = stX;
+        }
+    };
+
+    if (tq0 < ntq) {
+        tile_gload<D, NLD>(stQ, qbase, p.qs[2], tq0 * QT, p.Sq, tid);
+        tile_gload<D, NLD>(stD, dobase, bp.dos[2], tq0 * QT, p.Sq, tid);
+        stats_gload(tq0 * QT);
+        tile_lstore<D, NLD>(stQ, ldsQ, tid);
+        tile_lstore<D, NLD>(stD, ldsDO, tid);
+        stats_lstore(0);
+    }
+    __syncthreads();
+
+    for (int tq = tq0; tq < ntq; ++tq) {
+        const int buf = (tq - tq0) & 1;
+        const int r0 = tq * QT;
+        if (tq + 1 < ntq) {
+            tile_gload<D, NLD>(stQ, qbase, p.qs[2], r0 + QT, p.Sq, tid);
+            tile_gload<D, NLD>(stD, dobase, bp.dos[2], r0 + QT, p.Sq, tid);
+            stats_gload(r0 + QT);
+        }
+        const char* tQ = ldsQ + buf * TILEB;
+        const char* tD = ldsDO + buf * TILEB;
+        const float* tL = ldsLse + buf * QT;
+        const float* tX = ldsDlt + buf * QT;
+
+        // wave-uniform classification of (this q tile) x (this wave's keys [kw0, kw0+KB*32))
+        bool skip = false, need_mask = false;
+        if (causal) {
+            skip = (r0 + QT - 1 + coff) < kw0;                       // even the last row sees none of my keys
+            need_mask = (r0 + coff) < (kw0 + KB * 32 - 1);           // the first row does not see all my keys
+        }
+        if (r0 + QT > p.Sq || kw0 + KB * 32 > p.Sk) need_mask = true;
+        if (MODE == MODE_GENERAL) need_mask = true;
+
+        if (!skip) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                // S[q][key], dP[q][key] for 32 rows x KB*32 keys
+                f32x16 sacc[KB], pacc[KB];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        sacc[kb][r] = 0.f;
+                        pacc[kb][r] = 0.f;
+                    }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    vec8 qa = lds_read_rowfrag<E, D>(tQ, qb * 32 + l31, s, hi);
+                    vec8 da = lds_read_rowfrag<E, D>(tD, qb * 32 + l31, s, hi);
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        sacc[kb] = E::mfma(qa, kf[kb][s], sacc[kb]);
+                        pacc[kb] = E::mfma(da, vf[kb][s], pacc[kb]);
+                    }
+                }
+                // per-row statistics for the 16 rows this lane's registers cover
+                float lr[16], xr[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 a = *LDS_PTR(const f32x4, tL + qb * 32 + 8 * g + 4 * hi);
+                    f32x4 c = *LDS_PTR(const f32x4, tX + qb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lr[4 * g + e] = a[e];
+                        xr[4 * g + e] = c[e];
+                    }
+                }
+                vec8 pfr[KB][2], dsfr[KB][2];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const int key = kw0 + kb * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float y = sacc[kb][r] * p.c;
+                        bool show = true;
+                        if (need_mask) {
+                            const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            show = (key < p.Sk) && (row < p.Sq) && (!causal || key <= row + coff);
+                            if (MODE == MODE_GENERAL) {
+                                if (p.bias != nullptr && show) {
+                                    const int64_t bo = b * p.bs[0] + h * p.bs[1] + (int64_t)row * p.bs[2] + (int64_t)key * p.bs[3];
+                                    float bv;
+                                    if (p.bias_f32) bv = reinterpret_cast<const float*>(p.bias)[bo];
+                                    else bv = E::to_f32(reinterpret_cast<const uint16_t*>(p.bias)[bo]);
+                                    y = __builtin_fmaf(bv, kLog2e, y);
+                                }
+                                if (p.mask != nullptr && show) {
+                                    const int64_t mo = b * p.ms[0] + h * p.ms[1] + (int64_t)row * p.ms[2] + (int64_t)key * p.ms[3];
+                                    show = p.mask[mo] != 0;
+                                }
+                            }
+                        }
+                        float pv = fast_exp2(y - lr[r]);
+                        pv = show ? pv : 0.f;
+                        sacc[kb][r] = pv;
+                        pacc[kb][r] = pv * (pacc[kb][r] - xr[r]);
+                    }
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        f32x8 x, y;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            x[e] = sacc[kb][8 * t2 + e];
+                            y[e] = pacc[kb][8 * t2 + e];
+                        }
+                        pfr[kb][t2] = E::cvt8(x);
+                        dsfr[kb][t2] = E::cvt8(y);
+                    }
+                }
+                // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) {
+                        vec8 dot = lds_read_trfrag<E, D>(tD, qb * 32 + 16 * t2, d, lane);
+                        vec8 qt = lds_read_trfrag<E, D>(tQ, qb * 32 + 16 * t2, d, lane);
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb) {
+                            dvacc[kb][d] = E::mfma(dot, pfr[kb][t2], dvacc[kb][d]);
+                            dkacc[kb][d] = E::mfma(qt, dsfr[kb][t2], dkacc[kb][d]);
+                        }
+                    }
+            }
+        }
+        if (tq + 1 < ntq) {
+            tile_lstore<D, NLD>(stQ, ldsQ + (buf ^ 1) * TILEB, tid);
+            tile_lstore<D, NLD>(stD, ldsDO + (buf ^ 1) * TILEB, tid);
+            stats_lstore(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    char* dkbase = bp.dk + (b * bp.dks[0] + h * bp.dks[1]) * 2;
+    char* dvbase = bp.dv + (b * bp.dvs[0] + h * bp.dvs[1]) * 2;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int key = kw0 + kb * 32 + l31;
+        if (key < p.Sk) {
+            char* rk = dkbase + (int64_t)key * bp.dks[2] * 2;
+            char* rv = dvbase + (int64_t)key * bp.dvs[2] * 2;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 x, y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = dkacc[kb][d][4 * g + e] * bp.scale;
+                        y[e] = dvacc[kb][d][4 * g + e];
+                    }
+                    typename E::vec4 xk = E::cvt4(x), yv = E::cvt4(y);
+                    u32x2 ra, rb;
+                    __builtin_memcpy(&ra, &xk, 8);
+                    __builtin_memcpy(&rb, &yv, 8);
+                    gstore8(rk + (d * 32 + 8 * g + 4 * hi) * 2, ra);
+                    gstore8(rv + (d * 32 + 8 * g + 4 * hi) * 2, rb);
+                }
+        }
+    }
+}
+
+}  // namespace fasn

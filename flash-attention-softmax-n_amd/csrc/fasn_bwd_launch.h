@@ -1,0 +1,55 @@
+// fasn_bwd_launch.h — host-side launch plumbing for the backward kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fasn_bwd_kernel.h"
+#include "fasn_launch.h"
+
+namespace fasn {
+
+int launch_bwd(const BwdParams& p, const FwdLaunch& l, hipStream_t s);  // delta + dq + dkdv
+int launch_bwd_d32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
+int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
+int launch_bwd_d128(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
+
+template <typename K>
+inline void set_smem(K kern, int smem) {
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
+template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K>
+int launch_bwd_one(BwdParams p, hipStream_t s) {
+    const int nbh = p.f.B * p.f.H;
+    {   // delta
+        constexpr int RPB = 256 / (D / 8);
+        const int64_t rows = (int64_t)nbh * p.f.Sq;
+        hipLaunchKernelGGL((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
+    }
+    {   // dQ
+        constexpr int BM = 4 * QB * 32;
+        constexpr int smem = 4 * KT * D * 2;
+        p.nblk = (p.f.Sq + BM - 1) / BM;
+        auto kern = fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q>;
+        set_smem(kern, smem);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
+    }
+    {   // dK, dV
+        constexpr int BN = 4 * KB * 32;
+        constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4;
+        p.nblk = (p.f.Sk + BN - 1) / BN;
+        auto kern = fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K>;
+        set_smem(kern, smem);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+template <typename Tag, int D, int QB, int KB, int OCC_Q, int OCC_K>
+int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
+    switch (mode) {
+        case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K>(p, s);
+        case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K>(p, s);
+        default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, 1, 1>(p, s);
+    }
+}
+
+}  // namespace fasn

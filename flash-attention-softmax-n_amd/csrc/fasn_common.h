@@ -1,0 +1,159 @@
+// fasn_common.h — device-side building blocks shared by the forward and backward kernels.
+// gfx950 (CDNA4) only: wave64, v_mfma_f32_32x32x16_{bf16,f16}, ds_read_b64_tr_b16, v_permlane32_swap.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fasn {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+#define FASN_DEV __device__ __forceinline__
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct bf16_tag {};
+struct f16_tag {};
+
+// Element-type traits: the MFMA operand vector (8 x 16-bit = 4 VGPRs) and conversions.
+template <typename Tag>
+struct ET;
+
+template <>
+struct ET<bf16_tag> {
+    typedef bf16x8 vec8;
+    typedef bf16x4 vec4;
+    static FASN_DEV f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static FASN_DEV vec8 cvt8(f32x8 x) { return __builtin_convertvector(x, bf16x8); }
+    static FASN_DEV vec4 cvt4(f32x4 x) { return __builtin_convertvector(x, bf16x4); }
+    static FASN_DEV float to_f32(uint16_t bits) { return __uint_as_float(((uint32_t)bits) << 16); }
+};
+
+template <>
+struct ET<f16_tag> {
+    typedef f16x8 vec8;
+    typedef f16x4 vec4;
+    static FASN_DEV f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static FASN_DEV vec8 cvt8(f32x8 x) { return __builtin_convertvector(x, f16x8); }
+    static FASN_DEV vec4 cvt4(f32x4 x) { return __builtin_convertvector(x, f16x4); }
+    static FASN_DEV float to_f32(uint16_t bits) {
+        _Float16 h;
+        __builtin_memcpy(&h, &bits, 2);
+        return (float)h;
+    }
+};
+
+// ---- LDS tile image -------------------------------------------------------------------------
+// A tile is [rows][D] 16-bit elements, row-major, with the 16-byte chunks of each row XOR-permuted
+// so that BOTH access patterns below are bank-conflict free (bank = (addr/4) mod 64):
+//   (1) ds_read_b128 "row = lane&31, same chunk" (MFMA operand with the contraction along D),
+//       serviced in 16-lane groups {0-3,12-15,20-27},{4-11,16-19,28-31},...
+//   (2) ds_read_b64_tr_b16 "4 consecutive rows x 32 contiguous columns per half-wave"
+//       (MFMA operand with the contraction along rows), serviced per 32 lanes.
+// chunk' = chunk ^ f(row):
+//   D=128 (256-B rows, one bank-row each):  f = ((row&3)<<2) | ((row>>2)&3)
+//   D=64  (128-B rows, two per bank-row):   f = (bit1(row)<<2) | (bit2(row)<<1) | bit3(row)
+//   D=32  (64-B rows, four per bank-row):   f = (row>>2)&3
+template <int D>
+FASN_DEV int swz_f(int row) {
+    if constexpr (D == 128) {
+        return ((row & 3) << 2) | ((row >> 2) & 3);
+    } else if constexpr (D == 64) {
+        return ((row & 2) << 1) | ((row >> 1) & 2) | ((row >> 3) & 1);
+    } else {
+        static_assert(D == 32, "unsupported head dim");
+        return (row >> 2) & 3;
+    }
+}
+
+// byte offset of (row, 16-byte chunk) inside a tile image
+template <int D>
+FASN_DEV int tile_off(int row, int chunk) {
+    return row * (D * 2) + ((chunk ^ swz_f<D>(row)) << 4);
+}
+
+// MFMA operand "row = lane&31, k = 8*(lane>>5)+0..7" for k-step `ks` (16 columns per step):
+// one ds_read_b128 of chunk 2*ks + hi from row `row0 + (lane&31)`.
+template <typename E, int D>
+FASN_DEV typename E::vec8 lds_read_rowfrag(const char* tile, int row, int ks, int hi) {
+    const int off = tile_off<D>(row, 2 * ks + hi);
+    u32x4 raw = *LDS_PTR(const u32x4, tile + off);
+    typename E::vec8 r;
+    __builtin_memcpy(&r, &raw, 16);
+    return r;
+}
+
+// Transposed MFMA operand: "row(i) = column c0 + (lane&31) of the tile, k-slots = 8 tile rows".
+// The 8 rows are {rbase + 4*hi + 0..3} and {rbase + 8 + 4*hi + 0..3}: exactly the rows whose values
+// a lane with the same `hi` holds in registers 8t..8t+7 of a 32x32 MFMA accumulator (C layout
+// row = (r&3) + 8*(r>>2) + 4*hi), so accumulator registers feed the other operand with no shuffle.
+// Each ds_read_b64_tr_b16: within a 16-lane group, lane i supplies the address of 4 contiguous
+// elements = tile[row0 + (i>>2)][col0 + 4*(i&3) ..]; lane i receives tile[row0 + j][col0 + i], j=0..3.
+template <typename E, int D>
+FASN_DEV typename E::vec8 lds_read_trfrag(const char* tile, int rbase, int cblk, int lane) {
+    const int hi = lane >> 5;
+    const int i = lane & 15;
+    const int g1 = (lane >> 4) & 1;
+    const int col = cblk * 32 + g1 * 16 + 4 * (i & 3);  // element column of this lane's 4-element piece
+    const int chunk = col >> 3;
+    const int sub = (col & 7) * 2;  // 0 or 8 bytes
+    const int r0 = rbase + 4 * hi + (i >> 2);
+    const int r1 = r0 + 8;
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + tile_off<D>(r0, chunk) + sub));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + tile_off<D>(r1, chunk) + sub));
+    s16x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    typename E::vec8 r;
+    __builtin_memcpy(&r, &ab, 16);
+    return r;
+}
+
+// exchange a value between lane l and lane l^32 and return max(own, partner's)
+FASN_DEV float max_across_halves(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+FASN_DEV float sum_across_halves(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+FASN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// global 16-byte load / store helpers (pointers are 16-B aligned by the host-side contract)
+FASN_DEV u32x4 gload16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+FASN_DEV void gstore16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+FASN_DEV void gstore8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
+
+// XCD-aware block -> (batch*head, q-block) map. Blocks are dispatched round-robin over the 8 XCDs
+// (block b -> XCD b%8, observed, used for speed only): give every XCD whole heads so one head's
+// K/V stays in one XCD's L2.
+FASN_DEV void block_to_work(int bid, int nbh, int nblk_per_head, int& bh, int& blk) {
+    if ((nbh & 7) == 0) {
+        const int xcd = bid & 7;
+        const int j = bid >> 3;
+        bh = (j / nblk_per_head) * 8 + xcd;
+        blk = j % nblk_per_head;
+    } else {
+        bh = bid / nblk_per_head;
+        blk = bid % nblk_per_head;
+    }
+}
+
+}  // namespace fasn

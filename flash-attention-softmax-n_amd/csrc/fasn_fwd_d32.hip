@@ -1,0 +1,12 @@
+// D = 32 forward instantiations (QB=2: 256 query rows per workgroup).
+#include "fasn_launch.h"
+namespace fasn {
+template <typename Tag>
+static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (l.mode == MODE_GENERAL) return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, 1>(p, s);
+    return launch_fwd_mode<Tag, 32, 2, 2>(p, l.mode, s);
+}
+int launch_fwd_d32(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    return l.dtype == 1 ? go<bf16_tag>(p, l, s) : go<f16_tag>(p, l, s);
+}
+}  // namespace fasn

@@ -1,0 +1,337 @@
+// fasn_fwd_kernel.h — forward: tiled  S^T = K Q^T  ->  online softmax_n  ->  O^T += V^T P^T.
+//
+// Math (per (b,h), query row i), cf. reference flash_attention_softmax_n/core/functional.py:15-29,32-93:
+//   x_ij = scale * q_i.k_j + bias_ij     (masked / non-causal-visible -> -inf)
+//   LSE_i = log(n + sum_j exp(x_ij)),  P_ij = exp(x_ij - LSE_i),  O_i = sum_j P_ij v_j
+//
+// The "+n" is a virtual sink column with logit 0 and value 0 (what flash_attn.py:66-73 builds with
+// n zero-padded K/V rows, generalised to real n): the online-softmax state starts at
+// (m, l, acc) = (0, n, 0) instead of (-inf, 0, 0); the FA-2 recurrence is otherwise unchanged.
+//
+// Orientation. Everything is computed transposed so that ONE LANE OWNS ONE QUERY ROW end to end:
+//   S^T[key][q] = mfma(A = K rows (ds_read_b128), B = Q^T (registers))  -> lane (q=lane&31, hi) holds
+//                 keys (r&3) + 8*(r>>2) + 4*hi, r = 0..15, of each 32-key block
+//   row max / row sum: in-lane over its registers + one v_permlane32_swap with lane^32
+//   P^T: those same registers, exponentiated and packed to 16 bit, ARE the B operand of the next MFMA
+//   O^T[d][q] += mfma(A = V^T (ds_read_b64_tr_b16 with the matching key permutation), B = P^T)
+// so there is no LDS round trip and no cross-lane shuffle for P, and alpha/l/m are per-lane scalars.
+//
+// Work decomposition: workgroup = 4 waves = BM = 4*QB*32 query rows of one (b,h); each wave owns
+// QB 32-row blocks and reuses every K / V fragment it reads from LDS for all of them. K/V tiles of 64
+// keys are staged global -> registers -> swizzled LDS image, double buffered, one barrier per tile.
+#pragma once
+#include "fasn_common.h"
+
+namespace fasn {
+
+enum { MODE_PLAIN = 0, MODE_CAUSAL = 1, MODE_GENERAL = 2 };
+
+struct FwdParams {
+    const char* q;
+    const char* k;
+    const char* v;
+    char* o;
+    float* lse;
+    const uint8_t* mask;
+    const char* bias;
+    int64_t qs[3], ks[3], vs[3], os[3];  // element strides (batch, head, row); feature stride 1
+    int64_t ms[4], bs[4];                // mask / bias element strides (batch, head, q, key)
+    int B, H, Sq, Sk;
+    int nqblk;      // query blocks per head
+    int causal;
+    int bias_f32;   // bias elements are fp32 (else same 16-bit type as q)
+    float c;        // scale * log2(e)
+    float n;        // softmax_n
+};
+
+constexpr int KT = 64;  // keys per tile
+
+template <typename Tag, int D, int QB, int MODE, int OCC>
+__global__ void __launch_bounds__(256, OCC) fasn_fwd_kernel(const FwdParams p) {
+    using E = ET<Tag>;
+    using vec8 = typename E::vec8;
+    constexpr int NW = 4;
+    constexpr int BM = NW * QB * 32;
+    constexpr int ROWB = D * 2;
+    constexpr int TILEB = KT * ROWB;
+    constexpr int KS = D / 16;   // k-steps of QK^T
+    constexpr int DB = D / 32;   // 32-wide output column blocks
+    constexpr int CPR = D / 8;   // 16-B chunks per row
+    constexpr int NLD = (KT * CPR) / 256;  // staging loads per thread per tensor
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsK = smem;              // [2][TILEB]
+    char* const ldsV = smem + 2 * TILEB;  // [2][TILEB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+
+    int bh, qi;
+    block_to_work(blockIdx.x, p.B * p.H, p.nqblk, bh, qi);
+    // causal: heaviest (last) query blocks first
+    const int qblk = (MODE != MODE_PLAIN && p.causal) ? (p.nqblk - 1 - qi) : qi;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qblk * BM;
+    const int qw0 = q0 + wave * (QB * 32);  // first row of this wave
+
+    const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
+    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
+
+    const bool causal = (MODE == MODE_CAUSAL) || (MODE == MODE_GENERAL && p.causal);
+    const int coff = p.Sk - p.Sq;  // key j visible to row i iff j <= i + coff
+
+    // ---- number of K/V tiles this workgroup walks
+    int ntiles = (p.Sk + KT - 1) / KT;
+    if (causal) {
+        const int last_row = min(q0 + BM, p.Sq) - 1;
+        const int kmax = last_row + coff;  // last visible key of the block
+        const int nt_c = kmax < 0 ? 0 : (kmax / KT + 1);
+        ntiles = min(ntiles, nt_c);
+    }
+
+    // ---- Q fragments (B operand: col = q = lane&31, k = 8*hi..8*hi+7 of each 16-wide step)
+    vec8 qf[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int row = qw0 + qb * 32 + l31;
+        const bool ok = row < p.Sq;
+        const char* rp = qbase + (int64_t)row * p.qs[2] * 2 + hi * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 raw = {0u, 0u, 0u, 0u};
+            if (ok) raw = gload16(rp + s * 32);
+            __builtin_memcpy(&qf[qb][s], &raw, 16);
+        }
+    }
+
+    // ---- staging: each thread moves NLD 16-byte chunks of K and of V per tile
+    u32x4 stK[NLD], stV[NLD];
+    auto stage_load = [&](int t) {
+        const int k0 = t * KT;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ci = tid + i * 256;
+            const int row = ci / CPR, ch = ci % CPR;
+            const int key = k0 + row;
+            u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
+            if (key < p.Sk) {
+                zk = gload16(kbase + (int64_t)key * p.ks[2] * 2 + ch * 16);
+                zv = gload16(vbase + (int64_t)key * p.vs[2] * 2 + ch * 16);
+            }
+            stK[i] = zk;
+            stV[i] = zv;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ci = tid + i * 256;
+            const int row = ci / CPR, ch = ci % CPR;
+            const int off = tile_off<D>(row, ch);
+            *LDS_PTR(u32x4, ldsK + buf * TILEB + off) = stK[i];
+            *LDS_PTR(u32x4, ldsV + buf * TILEB + off) = stV[i];
+        }
+    };
+
+    // ---- online-softmax state, per lane = per query row (log2 domain: y = x * log2(e))
+    float m_run[QB], l_run[QB];
+    f32x16 oacc[QB][DB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const bool sink = p.n > 0.f;
+        m_run[qb] = sink ? 0.f : -INFINITY;
+        l_run[qb] = (sink && hi == 0) ? p.n : 0.f;  // the two half-lanes' partial sums are added at the end
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
+    }
+
+    if (ntiles > 0) {
+        stage_load(0);
+        stage_store(0);
+    }
+    __syncthreads();
+
+    // rows of this wave: [qw0, qw0 + QB*32)
+    const int wave_first_vis = qw0 + coff;                 // last visible key of the wave's first row
+    const int wave_last_vis = qw0 + QB * 32 - 1 + coff;    // last visible key of the wave's last row
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const int k0 = t * KT;
+        if (t + 1 < ntiles) stage_load(t + 1);
+
+        // wave-uniform tile classification
+        bool skip = false;       // no visible element for this wave
+        bool need_mask = false;  // some element needs the element-wise path
+        if (causal) {
+            skip = k0 > wave_last_vis;
+            need_mask = (k0 + KT - 1) > wave_first_vis;
+        }
+        if (k0 + KT > p.Sk) need_mask = true;
+        if (MODE == MODE_GENERAL) need_mask = true;
+
+        if (!skip) {
+            const char* tK = ldsK + buf * TILEB;
+            const char* tV = ldsV + buf * TILEB;
+
+            // ---- S^T = K Q^T : acc[qb][kb], 32 keys x 32 queries each
+            f32x16 sacc[QB][2];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
+                }
+            }
+
+            // ---- online softmax_n per query block
+            vec8 pf[QB][2][2];  // [qb][kb][t]: B operand of the PV MFMA
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const int row = qw0 + qb * 32 + l31;
+                float alpha, m_new;
+                if (!need_mask) {
+                    // fast path: max on raw scores, scale folded into the exp2 argument (c > 0)
+                    float mx = sacc[qb][0][0];
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][kb][r]);
+                    mx = max_across_halves(mx);
+                    m_new = fmaxf(m_run[qb], mx * p.c);
+                    alpha = fast_exp2(m_run[qb] - m_new);
+                    float rs = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float pv = fast_exp2(__builtin_fmaf(sacc[qb][kb][r], p.c, -m_new));
+                            sacc[qb][kb][r] = pv;
+                            rs += pv;
+                        }
+                    l_run[qb] = l_run[qb] * alpha + rs;
+                } else {
+                    // element-wise path: y = s*c + bias*log2e, -inf where hidden
+                    float mx = -INFINITY;
+                    const int vis = causal ? (row + coff) : 0x7fffffff;  // last visible key of this row
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            float y = sacc[qb][kb][r] * p.c;
+                            bool show = (key < p.Sk) && (key <= vis);
+                            if (MODE == MODE_GENERAL) {
+                                const bool inb = show && (row < p.Sq);
+                                if (p.bias != nullptr && inb) {
+                                    const int64_t bo = b * p.bs[0] + h * p.bs[1] + (int64_t)row * p.bs[2] + (int64_t)key * p.bs[3];
+                                    float bv;
+                                    if (p.bias_f32) bv = reinterpret_cast<const float*>(p.bias)[bo];
+                                    else bv = E::to_f32(reinterpret_cast<const uint16_t*>(p.bias)[bo]);
+                                    y = __builtin_fmaf(bv, kLog2e, y);
+                                }
+                                if (p.mask != nullptr && inb) {
+                                    const int64_t mo = b * p.ms[0] + h * p.ms[1] + (int64_t)row * p.ms[2] + (int64_t)key * p.ms[3];
+                                    show = p.mask[mo] != 0;
+                                }
+                            }
+                            y = show ? y : -INFINITY;
+                            sacc[qb][kb][r] = y;
+                            mx = fmaxf(mx, y);
+                        }
+                    mx = max_across_halves(mx);
+                    m_new = fmaxf(m_run[qb], mx);
+                    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully hidden so far
+                    alpha = fast_exp2(m_run[qb] - m_use);
+                    float rs = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float pv = fast_exp2(sacc[qb][kb][r] - m_use);
+                            sacc[qb][kb][r] = pv;
+                            rs += pv;
+                        }
+                    l_run[qb] = l_run[qb] * alpha + rs;
+                }
+                m_run[qb] = m_new;
+                // rescale the accumulator only when some row's max moved (wave-uniform branch)
+                if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                    for (int d = 0; d < DB; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
+                }
+                // pack P^T to 16 bit: registers 8t..8t+7 of key block kb -> k-slots of PV step (kb,t)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        f32x8 x;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = sacc[qb][kb][8 * t2 + e];
+                        pf[qb][kb][t2] = E::cvt8(x);
+                    }
+            }
+
+            // ---- O^T += V^T P^T
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) {
+                        vec8 vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, d, lane);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
+                    }
+        }
+
+        if (t + 1 < ntiles) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: O = acc / l, LSE = ln2 * (m + log2 l)
+    char* obase = p.o + (b * p.os[0] + h * p.os[1]) * 2;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int row = qw0 + qb * 32 + l31;
+        const float l_tot = sum_across_halves(l_run[qb]);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (row < p.Sq) {
+            if (p.lse != nullptr && hi == 0) {
+                const float m_use = (m_run[qb] == -INFINITY) ? 0.f : m_run[qb];
+                p.lse[(int64_t)bh * p.Sq + row] = l_tot > 0.f ? (m_use + __builtin_log2f(l_tot)) * kLn2 : -INFINITY;
+            }
+            char* rp = obase + (int64_t)row * p.os[2] * 2;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = oacc[qb][d][4 * g + e] * inv;
+                    typename E::vec4 y = E::cvt4(x);
+                    u32x2 raw;
+                    __builtin_memcpy(&raw, &y, 8);
+                    gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
+                }
+        }
+    }
+}
+
+}  // namespace fasn

@@ -1,0 +1,48 @@
+// fasn_launch.h — host-side launch plumbing shared by the per-head-dim translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fasn_fwd_kernel.h"
+
+namespace fasn {
+
+// tuning variant (internal, not part of the C ABI): selects QB (32-row query blocks per wave)
+struct FwdLaunch {
+    int dtype;    // FASN_DTYPE_*
+    int D;
+    int mode;     // MODE_*
+    int variant;  // 0 = default
+};
+
+int launch_fwd_d32(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
+int launch_fwd_d64(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
+int launch_fwd_d128(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
+
+
+template <typename Tag, int D, int QB, int MODE, int OCC>
+int launch_fwd_one(FwdParams p, hipStream_t s) {
+    constexpr int BM = 4 * QB * 32;
+    constexpr int smem = 4 * KT * D * 2;
+    p.nqblk = (p.Sq + BM - 1) / BM;
+    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC>;
+    if (smem > 48 * 1024) {
+        static bool done = false;  // benign race: idempotent attribute
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            done = true;
+        }
+    }
+    const dim3 grid((unsigned)(p.nqblk * p.B * p.H));
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+template <typename Tag, int D, int QB, int OCC>
+int launch_fwd_mode(const FwdParams& p, int mode, hipStream_t s) {
+    switch (mode) {
+        case MODE_PLAIN: return launch_fwd_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
+        case MODE_CAUSAL: return launch_fwd_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
+        default: return launch_fwd_one<Tag, D, QB, MODE_GENERAL, OCC>(p, s);
+    }
+}
+
+}  // namespace fasn

@@ -1,0 +1,139 @@
+/*
+ * fasn.h — C ABI of libfasn: fused attention with softmax_n for AMD MI355X (gfx950 / CDNA4).
+ *
+ *   softmax_n(x)_i = exp(x_i) / (n + sum_j exp(x_j)),   real n >= 0
+ *   O = softmax_n(scale * Q K^T + bias  [masked / causal -> -inf]) V
+ *
+ * This is the drop-in boundary for the reference's kernel-launch sites:
+ *   - flash_attention_softmax_n/core/flash_attn.py:115-124   (torch SDPA call on zero-row-padded K/V)
+ *   - flash_attention_softmax_n/core/flash_attn_triton.py:278-291  (_fwd_kernel launch)
+ *   - flash_attention_softmax_n/core/flash_attn_triton.py:316-335  (_bwd_preprocess + _bwd_kernel launches)
+ * Host code (Python, PyTorch-ROCm) normalises arguments and calls these entry points through ctypes;
+ * see INTEGRATION.md for the reference-side binding.
+ *
+ * Contract
+ *   - plain C, no torch types: device pointers, element strides, sizes.
+ *   - the library never allocates, frees or synchronises; every buffer (incl. workspace) is caller-owned.
+ *   - launches are asynchronous on the hipStream_t passed in (0 = default stream).
+ *   - stateless and re-entrant; the current HIP device must be the one owning the pointers.
+ *   - returns FASN_OK (0) or a negative FASN_E* code; never throws, never aborts.
+ *
+ * Tensor layout: 4-D (batch, head, seq, feature) addressed by element strides; the feature stride
+ * must be 1 and base pointers / other strides must keep every row 16-byte aligned. A stride of 0 is
+ * a broadcast dimension (mask, bias, and the head dimension of K/V for shared-KV layouts).
+ */
+#ifndef FASN_H_
+#define FASN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASN_ABI_VERSION 1
+
+/* error codes */
+#define FASN_OK 0
+#define FASN_EINVAL (-1)      /* NULL pointer / non-positive size / bad enum */
+#define FASN_EDTYPE (-2)      /* unsupported element type */
+#define FASN_EHEADDIM (-3)    /* unsupported head dimension (supported: 32, 64, 128; D == Dv) */
+#define FASN_EALIGN (-4)      /* pointer or stride breaks the 16-byte row alignment rule */
+#define FASN_ESTRIDE (-5)     /* feature stride != 1 */
+#define FASN_ELAUNCH (-6)     /* hipLaunchKernel / hipGetLastError failure */
+#define FASN_EUNSUPPORTED (-7)/* valid request this build does not implement (e.g. dropout) */
+#define FASN_EWORKSPACE (-8)  /* workspace missing or too small */
+
+/* element types of q/k/v/o/do/dq/dk/dv */
+#define FASN_DTYPE_F16 0
+#define FASN_DTYPE_BF16 1
+
+/* element type of the additive bias */
+#define FASN_BIAS_NONE 0
+#define FASN_BIAS_SAME 1 /* same dtype as q */
+#define FASN_BIAS_F32 2
+
+typedef void* fasn_stream_t; /* hipStream_t */
+
+/* One 4-D tensor view: ptr + element strides for (batch, head, row, col). */
+typedef struct fasn_view4 {
+    void* ptr;
+    int64_t stride[4];
+} fasn_view4;
+
+/*
+ * Forward. Replaces: _fwd_kernel launch (flash_attn_triton.py:278-291) and the SDPA call
+ * (flash_attn.py:117-124) including its K/V zero-row padding (:66-73) and dense mask
+ * materialisation (:87-113), which are expressed here as `softmax_n`, `causal`, `mask`, `bias`.
+ */
+typedef struct fasn_fwd_args {
+    fasn_view4 q;   /* [B,H,Sq,D]  */
+    fasn_view4 k;   /* [B,H,Sk,D]  */
+    fasn_view4 v;   /* [B,H,Sk,Dv] */
+    fasn_view4 o;   /* [B,H,Sq,Dv] out */
+    float* lse;     /* [B,H,Sq] fp32 contiguous, out: log(n + sum_j exp(x_ij)) (natural log); may be NULL */
+    fasn_view4 mask;/* optional, uint8/bool, nonzero = attend; strides may be 0; ptr NULL = none */
+    fasn_view4 bias;/* optional additive bias (added after scaling); ptr NULL = none */
+    int32_t bias_dtype; /* FASN_BIAS_* */
+    int32_t dtype;      /* FASN_DTYPE_* */
+    int32_t B, H, Sq, Sk, D, Dv;
+    float scale;        /* multiplies q.k before bias (reference default 1/sqrt(D)) */
+    float softmax_n;    /* n >= 0, real-valued */
+    int32_t causal;     /* bottom-right aligned: key j visible to row i iff j <= i + Sk - Sq */
+    float dropout_p;    /* must be 0 in ABI v1 (FASN_EUNSUPPORTED otherwise) */
+    uint64_t seed, offset; /* reserved for in-kernel Philox dropout */
+} fasn_fwd_args;
+
+/*
+ * Backward. Replaces _bwd_preprocess + _bwd_kernel (flash_attn_triton.py:316-335), with the
+ * softmax_n-correct LSE (the reference's Triton backward drops n).
+ * dq/dk/dv are written (not accumulated) in `dtype`. `delta` is a [B,H,Sq] fp32 scratch the
+ * caller provides; `workspace` must hold fasn_bwd_workspace_bytes() bytes (may be 0).
+ */
+typedef struct fasn_bwd_args {
+    fasn_fwd_args fwd; /* same views as forward; o and lse are inputs here */
+    fasn_view4 dout;   /* [B,H,Sq,Dv] */
+    fasn_view4 dq;     /* [B,H,Sq,D]  out */
+    fasn_view4 dk;     /* [B,H,Sk,D]  out */
+    fasn_view4 dv;     /* [B,H,Sk,Dv] out */
+    float* delta;      /* [B,H,Sq] fp32 scratch */
+    void* workspace;
+    size_t workspace_bytes;
+} fasn_bwd_args;
+
+int fasn_abi_version(void);
+const char* fasn_strerror(int code);
+
+/* 1 if (dtype, D, Dv) has a compiled kernel, else 0. */
+int fasn_supported(int32_t dtype, int32_t D, int32_t Dv);
+
+int fasn_fwd(const fasn_fwd_args* args, fasn_stream_t stream);
+
+size_t fasn_bwd_workspace_bytes(const fasn_bwd_args* args);
+int fasn_bwd(const fasn_bwd_args* args, fasn_stream_t stream);
+
+/*
+ * Stand-alone softmax_n over the last dimension of a [rows, cols] matrix (row stride in elements,
+ * col stride 1). Replaces flash_attention_softmax_n/core/functional.py:15-29 for device tensors.
+ * dtype: FASN_DTYPE_F16 / FASN_DTYPE_BF16 / 2 (= fp32).
+ */
+#define FASN_DTYPE_F32 2
+int fasn_softmax_n_fwd(const void* x, void* y, int64_t rows, int64_t cols, int64_t x_row_stride,
+                       int64_t y_row_stride, float n, int32_t dtype, fasn_stream_t stream);
+/* dx = y * (dy - sum_j dy_j y_j)  (same formula as softmax; n only enters through y) */
+int fasn_softmax_n_bwd(const void* y, const void* dy, void* dx, int64_t rows, int64_t cols,
+                       int64_t y_row_stride, int64_t dy_row_stride, int64_t dx_row_stride,
+                       int32_t dtype, fasn_stream_t stream);
+
+/* Timing helper for bench.py: elapsed milliseconds between two events recorded on `stream`
+ * around `iters` back-to-back forward launches (HIP events on the launch stream). */
+int fasn_time_fwd(const fasn_fwd_args* args, fasn_stream_t stream, int32_t warmup, int32_t iters,
+                  float* ms_per_iter);
+int fasn_time_bwd(const fasn_bwd_args* args, fasn_stream_t stream, int32_t warmup, int32_t iters,
+                  float* ms_per_iter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASN_H_ */
