@@ -1,0 +1,235 @@
+"""Host side of the hot path: the reference's attention API on top of libfasn (HIP, gfx950).
+
+Mirrors, argument for argument:
+  * flash_attention_n          — flash_attention_softmax_n/core/flash_attn.py:42-124
+  * flash_attention_n_triton   — flash_attention_softmax_n/core/flash_attn_triton.py:339-357
+  * slow_attention_n           — flash_attention_softmax_n/core/functional.py:32-93 (signature only; same kernel)
+What the reference does by materialising tensors is passed to the kernel as scalars and strides:
+  n zero-padded K/V rows (flash_attn.py:66-73)        -> `softmax_n` float (real-valued n allowed)
+  q * scale/default (flash_attn.py:81-83)             -> `scale` float, folded into the exp2 argument
+  dense [B,H,L,S] mask & bias (flash_attn.py:87-113)  -> broadcast strides (0 = broadcast), `causal` flag
+PyTorch is used for device memory, streams and autograd only.
+"""
+from math import sqrt
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import BwdArgs, FwdArgs, View4
+
+_SUPPORTED_D = (32, 64, 128)
+_DTYPES = {torch.float16: _lib.FASN_DTYPE_F16, torch.bfloat16: _lib.FASN_DTYPE_BF16}
+
+
+def _view4(t: Optional[Tensor]) -> View4:
+    v = View4()
+    if t is None:
+        v.ptr = None
+        return v
+    v.ptr = t.data_ptr()
+    for i in range(4):
+        v.stride[i] = t.stride(i) if t.size(i) > 1 else 0
+    v.stride[3] = 1 if t.size(3) == 1 else t.stride(3)
+    return v
+
+
+def _rows_ok(t: Tensor) -> bool:
+    """16-byte row alignment rule of the C ABI for 2-byte element tensors."""
+    if t.stride(-1) != 1 and t.size(-1) != 1:
+        return False
+    if t.data_ptr() % 16 != 0:
+        return False
+    return all(t.stride(i) % 8 == 0 or t.size(i) == 1 for i in range(t.dim() - 1))
+
+
+def _canon(t: Tensor) -> Tensor:
+    return t if _rows_ok(t) else t.contiguous()
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal):
+    a.q, a.k, a.v, a.o = _view4(q), _view4(k), _view4(v), _view4(o)
+    a.lse = lse.data_ptr()
+    a.mask = _view4(mask)
+    a.bias = _view4(bias)
+    if bias is not None:
+        a.bias_dtype = _lib.FASN_BIAS_F32 if bias.dtype == torch.float32 else _lib.FASN_BIAS_SAME
+    else:
+        a.bias_dtype = _lib.FASN_BIAS_NONE
+    a.dtype = _DTYPES[q.dtype]
+    a.B, a.H, a.Sq, a.D = q.shape
+    a.Sk = k.shape[2]
+    a.Dv = v.shape[3]
+    a.scale = scale
+    a.softmax_n = n
+    a.causal = 1 if causal else 0
+    a.dropout_p = 0.0
+    a.seed = 0
+    a.offset = 0
+
+
+class _FlashAttentionSoftmaxN(torch.autograd.Function):
+    """autograd glue; same role as _FlashAttentionN (flash_attn_triton.py:241-336)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, bias, n: float, scale: float, causal: bool):
+        lib = _lib.load()
+        B, H, L, D = q.shape
+        o = torch.empty((B, H, L, v.shape[3]), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+        a = FwdArgs()
+        _fill_fwd(a, q, k, v, o, lse, mask, bias, n, scale, causal)
+        with torch.cuda.device(q.device):
+            _lib.check(lib.fasn_fwd(a, _stream_ptr(q.device)), "fasn_fwd")
+        ctx.save_for_backward(q, k, v, o, lse, mask, bias)
+        ctx.n, ctx.scale, ctx.causal = n, scale, causal
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q, k, v, o, lse, mask, bias = ctx.saved_tensors
+        dout = _canon(dout)
+        B, H, L, D = q.shape
+        S = k.shape[2]
+        # K/V with a broadcast (stride-0) head dimension get per-head gradients that are summed below
+        dq = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
+        dk = torch.empty((B, H, S, D), dtype=q.dtype, device=q.device)
+        dv = torch.empty((B, H, S, v.shape[3]), dtype=q.dtype, device=q.device)
+        delta = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+        a = BwdArgs()
+        _fill_fwd(a.fwd, q, k, v, o, lse, mask, bias, ctx.n, ctx.scale, ctx.causal)
+        a.dout, a.dq, a.dk, a.dv = _view4(dout), _view4(dq), _view4(dk), _view4(dv)
+        a.delta = delta.data_ptr()
+        a.workspace = None
+        a.workspace_bytes = 0
+        with torch.cuda.device(q.device):
+            _lib.check(lib.fasn_bwd(a, _stream_ptr(q.device)), "fasn_bwd")
+        return dq, dk, dv, None, None, None, None, None
+
+
+def _pad_feature(t: Tensor, d: int) -> Tensor:
+    return t if t.shape[-1] == d else torch.nn.functional.pad(t, (0, d - t.shape[-1]))
+
+
+def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) -> Tensor:
+    if not query.is_cuda:
+        raise RuntimeError("flash_attention_softmax_n_amd runs on MI355X device tensors only; got a CPU tensor "
+                           "(there is deliberately no CPU fallback)")
+    if query.dtype not in _DTYPES:
+        raise NotImplementedError(f"dtype {query.dtype}: the gfx950 MFMA path supports torch.float16 and torch.bfloat16")
+    if key.dtype != query.dtype or value.dtype != query.dtype:
+        raise TypeError("query, key and value must share one dtype")
+    if dropout_p and dropout_p > 0.0:
+        raise NotImplementedError("dropout_p > 0 is not implemented in ABI v1 (SURVEY.md §8f rank 1)")
+    if query.dim() != 4:
+        raise ValueError("query must be [B, H, L, E]")
+    n = 0.0 if n is None else float(n)
+    if n < 0:
+        raise ValueError("softmax_n_param must be >= 0")
+    B, H, L, E = query.shape
+
+    # 3-D key/value [B, S, E] = one K/V shared by all heads: a stride-0 head dimension, no copy
+    if key.dim() == 3:
+        key = key.unsqueeze(1).expand(B, H, key.shape[1], key.shape[2])
+    if value.dim() == 3:
+        value = value.unsqueeze(1).expand(B, H, value.shape[1], value.shape[2])
+    S, Ev = key.shape[2], value.shape[3]
+    if key.shape[3] != E or value.shape[2] != S:
+        raise ValueError("key must be [B,H,S,E] and value [B,H,S,Ev]")
+    key = key.expand(B, H, S, E)
+    value = value.expand(B, H, S, Ev)
+
+    scale = (1.0 / sqrt(E)) if scale is None else float(scale)
+    if scale < 0:  # exp2 folding assumes scale >= 0: move the sign into q
+        query, scale = -query, -scale
+
+    # feature dims: kernels exist for D == Dv in {32, 64, 128}; anything else is zero-padded (exact)
+    dpad = next((d for d in _SUPPORTED_D if d >= max(E, Ev)), None)
+    if dpad is None:
+        raise NotImplementedError(f"head dim {max(E, Ev)} > 128 is not supported")
+    q, k, v = (_canon(_pad_feature(t, dpad)) for t in (query, key, value))
+
+    if mask is not None:
+        if mask.dim() != 4:
+            raise AssertionError("attn_mask must be 4-D and broadcastable to [B, H, L, S]")  # flash_attn.py:88
+        if mask.dtype != torch.bool:
+            raise TypeError("attn_mask must be boolean (True = attend); pass additive masks as attn_bias")
+        # bool -> uint8 reinterpretation keeps the (possibly stride-0) broadcast strides: no dense copy
+        mask = mask.expand(B, H, L, S).view(torch.uint8)
+    if bias is not None:
+        if bias.dim() == 3:
+            bias = bias.unsqueeze(0)  # [H,L,S] -> [1,H,L,S]  (flash_attn.py:101-102)
+        if bias.dim() != 4:
+            raise ValueError("attn_bias must be [H, L, S] or broadcastable to [B, H, L, S]")
+        if bias.dtype not in (query.dtype, torch.float32):
+            bias = bias.to(query.dtype)
+        bias = bias.expand(B, H, L, S)
+
+    out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal))
+    return out if Ev == dpad else out[..., :Ev]
+
+
+def flash_attention_n(
+        query: Tensor,
+        key: Tensor,
+        value: Tensor,
+        softmax_n_param: Optional[float] = None,
+        scale: Optional[float] = None,
+        dropout_p: float = 0.,
+        attn_mask: Optional[Tensor] = None,
+        attn_bias: Optional[Tensor] = None,
+        is_causal: bool = False
+) -> Tensor:
+    """Fused attention with softmax_n on MI355X; drop-in for flash_attention_softmax_n.flash_attention_n.
+
+    :param query: [B, H, L, E] fp16/bf16 device tensor.
+    :param key: [B, H, S, E] (or [B, S, E], shared by all heads).
+    :param value: [B, H, S, Ev].
+    :param softmax_n_param: n >= 0; real values allowed (the reference's SDPA path takes integers only).
+    :param scale: multiplies q.k^T; default 1/sqrt(E).
+    :param dropout_p: must be 0 (not implemented yet).
+    :param attn_mask: bool, 4-D, broadcastable to [B, H, L, S]; True = attend.
+    :param attn_bias: additive bias [H, L, S] or broadcastable to [B, H, L, S] (e.g. ALiBi); not differentiated.
+    :param is_causal: bottom-right aligned causal mask (key j visible to row i iff j <= i + S - L).
+    :return: [B, H, L, Ev] in query's dtype.
+    Rows with no visible key and n == 0 return 0 (the reference returns NaN there).
+    """
+    return _attention(query, key, value, softmax_n_param, scale, dropout_p, attn_mask, attn_bias, is_causal)
+
+
+def flash_attention_n_triton(query: Tensor, key: Tensor, value: Tensor, is_causal: bool = False,
+                             scale: Optional[float] = None, softmax_n_param: Optional[float] = None) -> Tensor:
+    """Signature of flash_attn_triton.py:339-345; served by the same HIP kernel (bf16 too, any L/S)."""
+    return _attention(query, key, value, softmax_n_param, scale, 0.0, None, None, is_causal)
+
+
+def slow_attention_n(query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[Tensor] = None, dropout_p: float = 0.0,
+                     is_causal: bool = False, scale: Optional[float] = None, softmax_n_param: Optional[float] = None,
+                     softmax_dtype=None, train: bool = True) -> Tensor:
+    """Signature of functional.py:32-42 on the fused kernel. Accepts (N, ..., L, E) with 3-D or 4-D inputs.
+    Float masks are additive (broadcast over leading dims), boolean masks hide keys (the reference's
+    eager version silently ignores boolean masks, functional.py:85-86)."""
+    if is_causal and attn_mask is not None:
+        raise AssertionError("attn_mask and is_causal are mutually exclusive")  # functional.py:79
+    squeeze = query.dim() == 3
+    if squeeze:
+        query, key, value = query.unsqueeze(1), key.unsqueeze(1), value.unsqueeze(1)
+    mask = bias = None
+    if attn_mask is not None:
+        am = attn_mask
+        while am.dim() < 4:
+            am = am.unsqueeze(0)
+        if am.dtype == torch.bool:
+            mask = am
+        else:
+            bias = am
+    p = dropout_p if train else 0.0
+    out = _attention(query, key, value, softmax_n_param, scale, p, mask, bias, is_causal)
+    # softmax_dtype: the fused kernel keeps the softmax in fp32 registers whatever is asked for
+    return out.squeeze(1) if squeeze else out

@@ -1,0 +1,127 @@
+"""C-ABI library checks that need no GPU: it loads, exports every symbol include/fasn.h declares, validates arguments
+(validation returns before any launch), and the host-side front end refuses what it cannot serve."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "fasn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fasn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol(pkg):
+    lib = ctypes.CDLL(pkg._lib.LIB_PATH)
+    names = _header_functions()
+    assert "fasn_fwd" in names and "fasn_bwd" in names and len(names) >= 10
+    for name in names:
+        assert hasattr(lib, name), f"libfasn.so does not export {name}"
+    assert set(pkg._lib.EXPORTS) == set(names)
+
+
+def test_abi_version_and_strerror(pkg):
+    lib = pkg._lib.load()
+    assert lib.fasn_abi_version() == 1
+    assert lib.fasn_strerror(0) == b"ok"
+    for code in range(-8, 0):
+        assert len(lib.fasn_strerror(code)) > 5
+    assert b"unknown" in lib.fasn_strerror(-99)
+
+
+def test_supported_matrix(pkg):
+    lib = pkg._lib.load()
+    for d in (32, 64, 128):
+        assert lib.fasn_supported(0, d, d) == 1 and lib.fasn_supported(1, d, d) == 1
+    assert lib.fasn_supported(1, 64, 32) == 0
+    assert lib.fasn_supported(1, 96, 96) == 0
+    assert lib.fasn_supported(2, 64, 64) == 0
+
+
+def _args(pkg, **over):
+    a = pkg._lib.FwdArgs()
+    buf = (ctypes.c_char * 4096)()
+    base = (ctypes.addressof(buf) + 15) & ~15
+    for v in (a.q, a.k, a.v, a.o):
+        v.ptr = base
+        v.stride[0], v.stride[1], v.stride[2], v.stride[3] = 64 * 8, 64 * 8, 64, 1
+    a.dtype, a.B, a.H, a.Sq, a.Sk, a.D, a.Dv = 1, 1, 1, 8, 8, 64, 64
+    a.scale, a.softmax_n = 0.125, 1.0
+    for k_, v_ in over.items():
+        setattr(a, k_, v_)
+    a._keep = buf
+    return a
+
+
+def test_argument_validation_codes(pkg):
+    lib = pkg._lib.load()
+    assert lib.fasn_fwd(None, None) == -1
+    assert lib.fasn_fwd(_args(pkg, B=0), None) == -1
+    assert lib.fasn_fwd(_args(pkg, dtype=2), None) == -2
+    assert lib.fasn_fwd(_args(pkg, D=96, Dv=96), None) == -3
+    assert lib.fasn_fwd(_args(pkg, dropout_p=0.1), None) == -7
+    assert lib.fasn_fwd(_args(pkg, softmax_n=-1.0), None) == -1
+    a = _args(pkg)
+    a.q.ptr = a.q.ptr + 2
+    assert lib.fasn_fwd(a, None) == -4
+    a = _args(pkg)
+    a.k.stride[2] = 65
+    assert lib.fasn_fwd(a, None) == -4
+    a = _args(pkg)
+    a.v.stride[3] = 2
+    assert lib.fasn_fwd(a, None) == -5
+    b = pkg._lib.BwdArgs()
+    assert lib.fasn_bwd(None, None) == -1
+    b.fwd = _args(pkg)
+    assert lib.fasn_bwd(b, None) == -1  # lse / delta missing
+    assert lib.fasn_softmax_n_fwd(None, None, 1, 1, 1, 1, 0.0, 0, None) == -1
+
+
+def test_front_end_refuses_cpu_and_unsupported(pkg):
+    q = torch.zeros(1, 1, 4, 32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.flash_attention_n(q, q, q)
+    with pytest.raises(RuntimeError):
+        pkg.softmax_n(torch.zeros(3, 3))
+    with pytest.raises(RuntimeError):
+        pkg.slow_attention_n(q[0], q[0], q[0])
+
+
+def test_missing_library_fails_loudly(pkg, monkeypatch):
+    monkeypatch.setattr(pkg._lib, "_lib", None)
+    monkeypatch.setattr(pkg._lib, "LIB_PATH", "/nonexistent/libfasn.so")
+    with pytest.raises(ImportError, match="no fallback"):
+        pkg._lib.load()
+
+
+def test_view_and_canon_helpers(pkg):
+    fa = pkg.flash_attn
+    t = torch.zeros(2, 3, 8, 64, dtype=torch.bfloat16)
+    v = fa._view4(t)
+    assert list(v.stride) == [3 * 8 * 64, 8 * 64, 64, 1]
+    e = torch.zeros(2, 1, 1, 16, dtype=torch.uint8).expand(2, 3, 8, 16)
+    assert list(fa._view4(e).stride) == [16, 0, 0, 1]
+    assert fa._rows_ok(t) and not fa._rows_ok(t.transpose(2, 3))
+    tt = t.permute(0, 2, 1, 3)  # [B, L, H, D] memory viewed as [B, H, L, D]: still row-aligned, no copy needed
+    assert fa._rows_ok(tt.permute(0, 2, 1, 3))
+    assert fa._canon(t.transpose(2, 3)).is_contiguous()
+    assert fa._pad_feature(t, 128).shape[-1] == 128 and fa._pad_feature(t, 64) is t
+
+
+def test_synth_is_index_addressable_and_deterministic(pkg):
+    s = pkg.synth if hasattr(pkg, "synth") else __import__("flash_attention_softmax_n_amd.synth", fromlist=["x"])
+    x = s.counter_normal((4, 256, 64), 5, dtype=torch.float16)
+    y = s.counter_normal((256, 64), 5, dtype=torch.float16, start=2 * 256 * 64)
+    assert torch.equal(x[2], y)
+    assert s.checksum(x) == s.checksum(s.counter_normal((4, 256, 64), 5, dtype=torch.float16, chunk=1000))
+    assert abs(x.float().std().item() - 0.5) < 0.01 and abs(x.float().mean().item()) < 0.01
+    z = s.exact16(s.counter_normal((1000,), 1, dtype=torch.float32))
+    assert torch.equal(z, z.bfloat16().float()) and torch.equal(z, z.half().float())
+    assert torch.allclose(s.alibi_slopes(8), torch.tensor([2.0 ** -(i + 1) for i in range(8)], dtype=torch.float64))
+    m = s.keypad_mask(4, 64)
+    assert m.shape == (4, 1, 1, 64) and m.sum(-1).flatten().tolist() == [64, 56, 48, 32]

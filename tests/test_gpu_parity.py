@@ -1,0 +1,346 @@
+"""Parity tests proper (-m gpu): the HIP path (Python front end -> ctypes -> C ABI -> gfx950 kernels) against the oracle on
+the same seeded inputs, against the committed golden fixtures (outputs of the real reference), and — at BASELINE.json's full
+sizes — through size-independent properties. Tolerances are the reference's own (tests/gpu/core/test_flash_attn.py:14:
+atol 1e-2 fp16 / 5e-2 bf16, rtol 0) plus tighter relative gates against the fp32 "true" answer."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle.ref_attention import analytic_answer, analytic_causal_answer, ref_attention_n
+
+import flash_attention_softmax_n_amd.synth as synth
+
+pytestmark = pytest.mark.gpu
+
+REF_ATOL = {torch.float16: 1e-2, torch.bfloat16: 5e-2}   # reference GPU test tolerances (rtol 0)
+REL_TRUE = {torch.float16: 2.0 ** -9, torch.bfloat16: 2.0 ** -6}  # vs fp32 oracle, relative to the tensor's max |x|
+
+
+def _rand(shape, dtype, dev, seed, std=0.5):
+    return synth.counter_normal(shape, seed, std=std, dtype=dtype, device=dev)
+
+
+def _check(got, want, dtype, what):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    err = (got - want).abs().max().item()
+    assert err <= REF_ATOL[dtype], f"{what}: max-abs {err:.3e} > reference atol {REF_ATOL[dtype]}"
+    lim = REL_TRUE[dtype] * max(want.abs().max().item(), 1e-3)
+    assert err <= lim, f"{what}: max-abs {err:.3e} > {lim:.3e} (relative gate)"
+
+
+def _oracle_fwd_bwd(q, k, v, do, **kw):
+    qc, kc, vc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v))
+    kw = {a: (b.detach().cpu() if torch.is_tensor(b) else b) for a, b in kw.items()}
+    o = ref_attention_n(qc, kc, vc, **kw)
+    o.backward(do.detach().cpu().float())
+    return o, qc.grad, kc.grad, vc.grad
+
+
+# ---------------------------------------------------------------- the reference's own GPU test, same grid
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("is_causal", [False, True])
+@pytest.mark.parametrize("scale", [None, 0.1, 0.5])
+@pytest.mark.parametrize("n", [0, 1, 4])
+def test_flash_attention_n_vs_oracle(pkg, dev, n, scale, is_causal, dtype):
+    """reference tests/gpu/core/test_flash_attn.py:10-48: shape (6,1,1024,64), fwd + dq/dk/dv"""
+    shape = (6, 1, 1024, 64)
+    q, k, v = (_rand(shape, dtype, dev, s).requires_grad_() for s in (1, 2, 3))
+    do = _rand(shape, dtype, dev, 4, std=1.0)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, scale=scale, is_causal=is_causal)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=float(n), scale=scale, is_causal=is_causal)
+    _check(out, o, dtype, "out")
+    _check(q.grad, dq, dtype, "dq")
+    _check(k.grad, dk, dtype, "dk")
+    _check(v.grad, dv, dtype, "dv")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("weight", [10, 3, 0.5, 0.04, 0.02, 0.01, 0, -0.01, -0.02, -0.04, -0.5, -3, -10])
+@pytest.mark.parametrize("n", [0, 1, 4])
+def test_flash_attention_analytic(pkg, dev, n, weight, dtype):
+    """reference tests/gpu/core/test_flash_attn.py:51-91: Q=K=V=w, N=6, L=1024, S=1152 (L != S), scale 0.3, atol 1e-3"""
+    N, L, S, E, scale = 6, 1024, 1152, 64, 0.3
+    q = weight * torch.ones(N, 1, L, E, device=dev, dtype=dtype)
+    k = weight * torch.ones(N, 1, S, E, device=dev, dtype=dtype)
+    v = weight * torch.ones(N, 1, S, E, device=dev, dtype=dtype)
+    w = float(q[0, 0, 0, 0])  # the weight after rounding to dtype
+    a = pkg.flash_attention_n(q, k, v, scale=scale, softmax_n_param=n).float().cpu()
+    want = analytic_answer(w, S, E, scale, n)
+    assert (a - want).abs().max().item() <= 1e-3 + 2.0 ** -8 * abs(want)
+    b = pkg.flash_attention_n(q, k, v, scale=scale, softmax_n_param=n, is_causal=True).float().cpu()
+    wantc = torch.tensor(analytic_causal_answer(w, L, S, E, scale, n))
+    rtol = 2e-2 if dtype == torch.bfloat16 else 2e-3
+    got = b.sum(dim=0).sum(dim=-1)[0]
+    assert torch.allclose(got, N * E * wantc, rtol=rtol, atol=1e-3)
+
+
+# ---------------------------------------------------------------- golden fixtures (outputs of the real reference)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("n", [0.0, 0.5, 1.0, 4.0])
+def test_golden_g1(pkg, dev, golden_dir, n, causal, dtype):
+    """BASELINE config 1 (2,2,128,32): the inputs are exact in both 16-bit types, so the only error is the kernel's own"""
+    g = np.load(os.path.join(golden_dir, "g1_c1.npz"))
+    tag = f"n{n}_c{int(causal)}"
+    q, k, v = (torch.from_numpy(g[x]).to(dtype).to(dev).requires_grad_() for x in ("q", "k", "v"))
+    for x, t in (("q", q), ("k", k), ("v", v)):
+        assert torch.equal(t.detach().float().cpu(), torch.from_numpy(g[x]))  # exactly representable
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal)
+    out.backward(torch.from_numpy(g["dout"]).to(dtype).to(dev))
+    _check(out, torch.from_numpy(g[f"o_{tag}"]), dtype, "o")
+    _check(q.grad, torch.from_numpy(g[f"dq_{tag}"]), dtype, "dq")
+    _check(k.grad, torch.from_numpy(g[f"dk_{tag}"]), dtype, "dk")
+    _check(v.grad, torch.from_numpy(g[f"dv_{tag}"]), dtype, "dv")
+    if dtype == torch.bfloat16:  # what the reference's tests compare against: its own bf16-eager output, atol 5e-2
+        assert (out.detach().float().cpu() - torch.from_numpy(g[f"o_bf16native_{tag}"])).abs().max().item() <= 5e-2
+
+
+G4 = {"c2": torch.bfloat16, "c3": torch.float16, "m0": torch.bfloat16, "c4": torch.bfloat16, "c5": torch.bfloat16}
+SEEDS = {"q": 101, "k": 102, "v": 103, "dout": 104}
+
+
+def _full(name, shape, dtype, dev):
+    return synth.counter_normal(shape, SEEDS[name], std=1.0 if name == "dout" else 0.5, dtype=dtype, device=dev)
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "m0", "c4", "c5"])
+def test_golden_g4_full_size_sampled_rows(pkg, dev, golden_dir, cfg):
+    """BASELINE configs at FULL size; sampled rows of 4 (b,h) heads against the reference's slow_attention_n"""
+    g = np.load(os.path.join(golden_dir, f"g4_{cfg}.npz"))
+    dtype = G4[cfg]
+    B, H, S, D = (int(x) for x in g["shape"])
+    n, causal = float(g["n"]), bool(g["causal"])
+    q, k, v = (_full(nm, (B, H, S, D), dtype, dev) for nm in ("q", "k", "v"))
+    for hi, (b, h) in enumerate(g["heads"]):  # generator produced the fixture's bits on this machine too
+        assert [synth.checksum(t[int(b), int(h)]) for t in (q, k, v)] == list(g["checksums"][hi])
+    bias = mask = None
+    if cfg == "c4":
+        bias = synth.alibi_bias(H, S, S, dtype, device=dev)      # dense [H,L,S], as the reference requires
+        mask = synth.keypad_mask(B, S, device=dev)               # [B,1,1,S]
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal, attn_mask=mask, attn_bias=bias)
+    rows = torch.from_numpy(g["rows"]).to(dev)
+    for hi, (b, h) in enumerate(g["heads"]):
+        got = out[int(b), int(h)][rows].float().cpu()
+        true = torch.from_numpy(g["o_f32"][hi])
+        native = torch.from_numpy(g["o_native"][hi])
+        assert (got - native).abs().max().item() <= REF_ATOL[dtype]   # the reference-test criterion
+        assert (got - native).abs().max().item() < 1e-2              # north_star: max-abs < 1e-2 vs slow_attention_n
+        err = (got - true).abs().max().item()
+        rms = true.pow(2).mean().sqrt().item()
+        gate = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10) * max(true.abs().max().item(), 4 * rms)
+        assert err <= gate, f"{cfg} head {hi}: max-abs {err:.3e} vs fp32 oracle > {gate:.3e}"
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "m0", "c4"])
+def test_golden_g5_backward_rows(pkg, dev, golden_dir, cfg):
+    g = np.load(os.path.join(golden_dir, f"g5_{cfg}.npz"))
+    dtype = G4[cfg]
+    B, H, S, D = (int(x) for x in g["shape"])
+    b, h = (int(x) for x in g["head"])
+    n, causal = float(g["n"]), bool(g["causal"])
+    start = ((b * H + h) * S) * D
+    q, k, v, do = (synth.counter_normal((1, 1, S, D), SEEDS[nm], std=1.0 if nm == "dout" else 0.5, dtype=dtype, device=dev, start=start)
+                   for nm in ("q", "k", "v", "dout"))
+    assert [synth.checksum(t) for t in (q, k, v, do)] == list(g["checksums"])
+    bias = mask = None
+    if cfg == "c4":
+        bias = synth.alibi_bias_rows(H, S, S, [h], np.arange(S), dtype).to(dev)   # [1,S,S]
+        mask = synth.keypad_mask(B, S, device=dev)[b:b + 1]
+    q.requires_grad_(), k.requires_grad_(), v.requires_grad_()
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal, attn_mask=mask, attn_bias=bias)
+    out.backward(do)
+    rows = torch.from_numpy(g["rows"]).to(dev)
+    _check(out[0, 0][rows], torch.from_numpy(g["o"]), dtype, "o")
+    _check(q.grad[0, 0][rows], torch.from_numpy(g["dq"]), dtype, "dq")
+    _check(k.grad[0, 0][rows], torch.from_numpy(g["dk"]), dtype, "dk")
+    _check(v.grad[0, 0][rows], torch.from_numpy(g["dv"]), dtype, "dv")
+
+
+# ---------------------------------------------------------------- masks, bias, layouts, edge cases
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("kind", ["keypad", "dense", "bias3d", "bias4d_f32", "all"])
+def test_mask_bias_combinations(pkg, dev, kind, D, dtype):
+    B, H, L, S = 2, 3, 200, 264
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    mask = bias = None
+    causal = kind == "all"
+    gen = torch.Generator().manual_seed(5)
+    if kind in ("keypad", "all"):
+        mask = synth.keypad_mask(B, S, device=dev)
+    if kind == "dense":
+        mask = (torch.rand(B, H, L, S, generator=gen) < 0.7).to(dev)
+        mask[..., 0] = True
+    if kind in ("bias3d", "all"):
+        bias = torch.randn(H, L, S, generator=gen).to(dtype).to(dev)
+    if kind == "bias4d_f32":
+        bias = torch.randn(B, 1, L, S, generator=gen).to(dev)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, attn_mask=mask, attn_bias=bias, is_causal=causal)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=0.5, attn_mask=mask, is_causal=causal,
+                                    attn_bias=None if bias is None else bias.float())
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"{kind}/{nm}")
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 3, 8), (1, 2, 1, 64), (1, 1, 65, 16), (3, 2, 127, 96), (1, 1, 257, 40)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_ragged_and_padded_feature_dims(pkg, dev, shape, causal):
+    """tiny / ragged lengths and head dims that are zero-padded to a kernel size; (2,1,3,8) is the reference CPU test shape
+    (tests/cpu/core/test_flash_attn.py:12-13)"""
+    dtype = torch.bfloat16
+    B, H, L, E = shape
+    S, Ev = L + 5, E
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, E), 1), ((B, H, S, E), 2), ((B, H, S, Ev), 3)))
+    do = _rand((B, H, L, Ev), dtype, dev, 4, std=1.0)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1, is_causal=causal)
+    assert out.shape == (B, H, L, Ev)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0, is_causal=causal)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, nm)
+
+
+def test_value_dim_differs_and_shared_kv(pkg, dev):
+    """Ev != E (reference README.md:50) and 3-D key/value shared by all heads (flash_attn.py:75-79)"""
+    dtype = torch.float16
+    B, H, L, S, E, Ev = 2, 4, 100, 130, 64, 32
+    q = _rand((B, H, L, E), dtype, dev, 1).requires_grad_()
+    k = _rand((B, S, E), dtype, dev, 2).requires_grad_()
+    v = _rand((B, S, Ev), dtype, dev, 3).requires_grad_()
+    do = _rand((B, H, L, Ev), dtype, dev, 4, std=1.0)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=2)
+    out.backward(do)
+    qc, kc, vc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v))
+    o = ref_attention_n(qc, kc.unsqueeze(1), vc.unsqueeze(1), softmax_n_param=2.0)
+    o.backward(do.cpu().float())
+    for got, want, nm in ((out, o, "out"), (q.grad, qc.grad, "dq"), (k.grad, kc.grad, "dk"), (v.grad, vc.grad, "dv")):
+        _check(got, want, dtype, nm)
+
+
+def test_strided_layout_without_copy(pkg, dev):
+    """[B, L, H, D] memory viewed as [B, H, L, D] goes to the kernel through strides"""
+    dtype = torch.bfloat16
+    B, H, L, D = 2, 4, 192, 64
+    qkv = _rand((B, L, 3, H, D), dtype, dev, 9)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    assert not q.is_contiguous()
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1, is_causal=True)
+    o = ref_attention_n(q.cpu().float(), k.cpu().float(), v.cpu().float(), softmax_n_param=1.0, is_causal=True)
+    _check(out, o, dtype, "out")
+
+
+def test_fully_hidden_rows_give_zero(pkg, dev):
+    dtype = torch.float16
+    q, k, v = (_rand((1, 2, 64, 64), dtype, dev, s) for s in (1, 2, 3))
+    mask = torch.ones(1, 1, 64, 64, dtype=torch.bool, device=dev)
+    mask[:, :, 10] = False
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=0, attn_mask=mask)
+    assert torch.isfinite(out).all() and out[:, :, 10].abs().max().item() == 0.0
+    # Sq > Sk causal: the first Sq - Sk rows see nothing
+    out = pkg.flash_attention_n(q, k[:, :, :40], v[:, :, :40], softmax_n_param=0, is_causal=True)
+    assert out[:, :, :24].abs().max().item() == 0.0 and torch.isfinite(out).all()
+
+
+def test_real_valued_n_and_signature_aliases(pkg, dev):
+    dtype = torch.bfloat16
+    q, k, v = (_rand((2, 2, 128, 64), dtype, dev, s) for s in (1, 2, 3))
+    for n in (1e-6, 1e-3, 0.5, 3.0):
+        a = pkg.flash_attention_n(q, k, v, softmax_n_param=n)
+        b = pkg.flash_attention_n_triton(q, k, v, False, None, n)
+        c = pkg.slow_attention_n(q, k, v, softmax_n_param=n)
+        assert torch.equal(a, b) and torch.equal(a, c)
+        _check(a, ref_attention_n(q.cpu().float(), k.cpu().float(), v.cpu().float(), softmax_n_param=n), dtype, f"n={n}")
+    fm = torch.randn(128, 128).to(dev)
+    d = pkg.slow_attention_n(q[0], k[0], v[0], attn_mask=fm, softmax_n_param=1.0)   # 3-D inputs + (L,S) float mask
+    _check(d, ref_attention_n(q[0].cpu().float(), k[0].cpu().float(), v[0].cpu().float(), softmax_n_param=1.0, attn_bias=fm.cpu()),
+           dtype, "slow float mask")
+    with pytest.raises(NotImplementedError):
+        pkg.flash_attention_n(q, k, v, dropout_p=0.2)
+    with pytest.raises(NotImplementedError):
+        pkg.flash_attention_n(q.float(), k.float(), v.float())
+
+
+# ---------------------------------------------------------------- size-independent properties at full BASELINE sizes
+@pytest.mark.parametrize("cfg", ["m0", "c3"])
+def test_properties_at_full_size(pkg, dev, cfg):
+    dtype = G4[cfg]
+    B, H, S, D = 8, 16, 4096, 64
+    causal = cfg == "c3"
+    q, k, v = (_full(nm, (B, H, S, D), dtype, dev) for nm in ("q", "k", "v"))
+    fa = pkg.flash_attn
+    o1 = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, is_causal=causal)
+    assert torch.isfinite(o1).all()
+    # (1) determinism / idempotence: same launch, same bits
+    assert torch.equal(o1, pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, is_causal=causal))
+    # (2) linearity in V: O(2V) == 2 O(V) exactly (power-of-two scaling commutes with every rounding)
+    o2 = pkg.flash_attention_n(q, k, 2 * v, softmax_n_param=1.0, is_causal=causal)
+    if dtype == torch.bfloat16:
+        assert torch.equal(o2, 2 * o1)
+    else:  # fp16 subnormal outputs (< 6e-5) may round one 2^-24 step differently
+        assert (o2.float() - 2 * o1.float()).abs().max().item() <= 2.0 ** -23
+    # (3) softmax_n vs softmax_0:  O_n = O_0 * exp(LSE_0 - LSE_n),  exp(LSE_n) = n + exp(LSE_0)
+    def fwd_lse(n):
+        o = torch.empty_like(q)
+        lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+        a = pkg._lib.FwdArgs()
+        fa._fill_fwd(a, q, k, v, o, lse, None, None, n, 1.0 / D ** 0.5, causal)
+        pkg._lib.check(pkg._lib.load().fasn_fwd(a, torch.cuda.current_stream().cuda_stream), "fasn_fwd")
+        return o, lse
+    o0, lse0 = fwd_lse(0.0)
+    on, lsen = fwd_lse(1.0)
+    assert torch.allclose(torch.exp(lsen.double()), 1.0 + torch.exp(lse0.double()), rtol=1e-5)
+    pred = o0.float() * torch.exp(lse0 - lsen).unsqueeze(-1)
+    tol = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * o0.float().abs().max().item()
+    assert (on.float() - pred).abs().max().item() <= tol
+    if not causal:
+        # (4) key-permutation invariance (non-causal): permuting K and V rows together changes only summation order
+        perm = torch.randperm(S, device=dev)
+        op = pkg.flash_attention_n(q, k[:, :, perm], v[:, :, perm], softmax_n_param=1.0)
+        assert (op.float() - o1.float()).abs().max().item() <= tol
+    else:
+        # (4') causality: the first 1024 rows do not depend on later keys
+        oc = pkg.flash_attention_n(q[:, :, :1024], k[:, :, :1024], v[:, :, :1024], softmax_n_param=1.0, is_causal=True)
+        assert (oc.float() - o1[:, :, :1024].float()).abs().max().item() <= tol
+
+
+def test_c_oracle_cross_check_midsize(pkg, dev):
+    """independent fp64-accumulating C oracle at (2,4,512,64) with n=0.5, causal"""
+    dtype = torch.bfloat16
+    q, k, v = (_rand((2, 4, 512, 64), dtype, dev, s) for s in (1, 2, 3))
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, is_causal=True).float().cpu().numpy()
+    ref = c_oracle.attention_n(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(), n=0.5, causal=True)
+    assert np.abs(out - ref).max() <= 2.0 ** -7 * np.abs(ref).max()
+
+
+# ---------------------------------------------------------------- stand-alone softmax_n kernel
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n", [0.0, 1.0, 1e-3, 4.0])
+def test_softmax_n_kernel(pkg, dev, golden_dir, n, dtype):
+    g = np.load(os.path.join(golden_dir, "g3_softmax.npz"))
+    if dtype == torch.float32:
+        y = pkg.softmax_n(torch.from_numpy(g["x"]).to(dev), n=n)
+        assert np.allclose(y.cpu().numpy(), g[f"y_n{n}"], rtol=1e-5, atol=1e-7)
+        big = pkg.softmax_n(torch.from_numpy(g["big"]).to(dev), n)
+        assert abs(big.sum().item() - 1.0) <= 1e-6
+    x = synth.counter_normal((7, 33, 1000), 3, std=2.0, dtype=dtype, device=dev).requires_grad_()
+    y = pkg.softmax_n(x, n=n, dim=-1)
+    dy = synth.counter_normal((7, 33, 1000), 4, std=1.0, dtype=dtype, device=dev)
+    y.backward(dy)
+    xc = x.detach().cpu().float().requires_grad_()
+    from oracle.ref_attention import ref_softmax_n
+    yc = ref_softmax_n(xc, n=n)
+    yc.backward(dy.cpu().float())
+    tol = {torch.float32: 5e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    assert (y.detach().cpu().float() - yc.detach()).abs().max().item() <= tol * max(yc.abs().max().item(), 1e-3) + 1e-7
+    assert (x.grad.cpu().float() - xc.grad).abs().max().item() <= 4 * tol * max(xc.grad.abs().max().item(), 1e-3) + 1e-7
+    z = pkg.softmax_n(x.detach().transpose(1, 2), n=n, dim=1)  # non-last dim
+    assert torch.allclose(z.transpose(1, 2).float(), y.detach().float(), atol=1e-6)
+    w = synth.counter_normal((3, 5000), 5, std=3.0, dtype=dtype, device=dev)  # cols > register cache
+    assert torch.allclose(pkg.softmax_n(w, n=n).float().cpu(), ref_softmax_n(w.cpu().float(), n=n), atol=tol, rtol=tol)
