@@ -71,6 +71,12 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     p.causal = a->causal ? 1 : 0;
     p.bias_f32 = (a->bias.ptr && a->bias_dtype == FASN_BIAS_F32) ? 1 : 0;
     p.c = a->scale * kLog2e;
+    {
+        const int64_t kb = (int64_t)a->Sk * a->k.stride[2] * 2, vb = (int64_t)a->Sk * a->v.stride[2] * 2;
+        if (kb <= 0 || vb <= 0 || kb >= (1ll << 31) || vb >= (1ll << 31)) return FASN_EINVAL;  // one (b,h) K/V matrix must span < 2 GiB
+        p.kbytes = (unsigned)kb;
+        p.vbytes = (unsigned)vb;
+    }
     p.n = a->softmax_n;
 
     l.dtype = a->dtype;

@@ -171,6 +171,16 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         tile_lstore<D, NLD>(stV, ldsV, tid);
     }
     __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            retire_loads(qf[qb][s]);
+            retire_loads(dof[qb][s]);
+        }
+        retire_loads(lse2[qb]);
+        retire_loads(dlt[qb]);
+    }
 
     const int wave_first_vis = qw0 + coff;
     const int wave_last_vis = qw0 + QB * 32 - 1 + coff;
@@ -410,6 +420,13 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         stats_lstore(0);
     }
     __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            retire_loads(kf[kb][s]);
+            retire_loads(vf[kb][s]);
+        }
 
     for (int tq = tq0; tq < ntq; ++tq) {
         const int buf = (tq - tq0) & 1;

@@ -134,6 +134,14 @@ FASN_DEV float sum_across_halves(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Retire the global loads that filled loop-invariant register operands BEFORE a pipelined loop. Without this, hipcc's
+// first in-loop use of such a register carries `s_waitcnt vmcnt(0)`, which on every iteration also drains the K/V
+// prefetch issued a few instructions earlier (vmcnt only counts, it cannot tell old loads from new ones).
+template <typename V>
+FASN_DEV void retire_loads(V& v) {
+    asm volatile("" : "+v"(v));
+}
+
 FASN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // global 16-byte load / store helpers (pointers are 16-B aligned by the host-side contract)

@@ -1,17 +1,41 @@
-// D = 64 forward instantiations. variant selects the tuning point (internal; ABI callers get variant 0):
-//   0: QB=2 (64 rows/wave, 256 rows/WG), 2 waves/SIMD     1: QB=1 (128 rows/WG), 3 waves/SIMD
-//   2: QB=2, 1 wave/SIMD (512 registers)                  3: QB=1, 2 waves/SIMD
+// D = 64 forward instantiations. variant 0 = auto (the only value the C ABI uses); other values select a tuning
+// point or a developer ablation for A/B runs through tools/fasn_harness (see the switch below).
 #include "fasn_launch.h"
 namespace fasn {
 template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     const bool gen = l.mode == MODE_GENERAL;
-    switch (l.variant) {
+    int v = l.variant;
+    if (v == 0) {
+        // auto (what ABI callers get), measured on MI355X at (8,16,4096,64):
+        //   plain : QB=2, 2 waves/SIMD 882 TFLOP/s  vs QB=1, 3 waves/SIMD 835   -> QB=2 unless the grid would be too small
+        //   causal: QB=1, 3 waves/SIMD 639 TFLOP/s  vs QB=2 503 (finer diagonal, better tail balance)
+        const long blocks_qb2 = (long)((p.Sq + 255) / 256) * p.B * p.H;
+        v = (l.mode == MODE_PLAIN && blocks_qb2 >= 1024) ? 100 : 1;
+    }
+    switch (v) {
+        // ---- production tuning points
+        case 100: return gen ? launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 2, 2>(p, l.mode, s);
         case 1: return gen ? launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);
+        // ---- alternatives kept for A/B measurements (tools/fasn_harness bench ... <variant>)
         case 2: return gen ? launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 2, 1>(p, l.mode, s);
         case 3: return gen ? launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 1, 2>(p, l.mode, s);
-        default: return gen ? launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 2, 2>(p, l.mode, s);
+        case 4: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 1, 2>(p, l.mode, s); break;
+        case 6: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 2, 1>(p, l.mode, s); break;
+        case 9: if (!gen) return launch_fwd_pp_mode<Tag, 64, 2>(p, l.mode, s); break;
+        case 13: if (!gen) return launch_fwd_w8_mode<Tag, 64, 2, 2, 0>(p, l.mode, s); break;
+        case 15: if (!gen) return launch_fwd_w8_mode<Tag, 64, 1, 4, 0>(p, l.mode, s); break;
+        case 16: if (!gen) return launch_fwd_w8_mode<Tag, 64, 1, 4, 1>(p, l.mode, s); break;
+        // ---- ablations (plain mode only; results are NOT attention outputs)
+        case 21: return launch_fwd_abl<Tag, 64, 2, 2, 1>(p, s);
+        case 23: return launch_fwd_abl<Tag, 64, 2, 2, 3>(p, s);
+        case 25: return launch_fwd_abl<Tag, 64, 2, 2, 5>(p, s);
+        case 26: return launch_fwd_abl<Tag, 64, 2, 2, 6>(p, s);
+        case 28: return launch_fwd_abl<Tag, 64, 2, 2, 8>(p, s);
+        case 29: return launch_fwd_abl<Tag, 64, 2, 2, 9>(p, s);
+        default: break;
     }
+    return gen ? launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);
 }
 int launch_fwd_d64(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     return l.dtype == 1 ? go<bf16_tag>(p, l, s) : go<f16_tag>(p, l, s);

@@ -40,24 +40,31 @@ struct FwdParams {
     int nqblk;      // query blocks per head
     int causal;
     int bias_f32;   // bias elements are fp32 (else same 16-bit type as q)
+    unsigned kbytes, vbytes;  // byte extent of one (b,h) K / V matrix: Sk * row_stride * 2 (buffer descriptor range)
     float c;        // scale * log2(e)
     float n;        // softmax_n
 };
 
 constexpr int KT = 64;  // keys per tile
+// fast-path guard: a lane's partial row sum over one tile (32 values) must stay <= 2^8; any single p > 2^8 trips it
+constexpr float kSumLimit = 256.0f;
 
-template <typename Tag, int D, int QB, int MODE, int OCC>
-__global__ void __launch_bounds__(256, OCC) fasn_fwd_kernel(const FwdParams p) {
+// ABL (developer ablation, never dispatched by the ABI): 1 = no exponentials (P := raw S), 2 = no QK^T MFMAs,
+// 3 = no PV MFMAs, 4 = neither MFMA group, 5 = no K/V LDS fragment reads, 6 = no staging and no barrier,
+// 7 = 5 + 6, 8 = barrier but no staging, 9 = staging but no barrier
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0>
+__global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
-    constexpr int NW = 4;
+    constexpr int NT = NW * 64;
     constexpr int BM = NW * QB * 32;
     constexpr int ROWB = D * 2;
     constexpr int TILEB = KT * ROWB;
     constexpr int KS = D / 16;   // k-steps of QK^T
     constexpr int DB = D / 32;   // 32-wide output column blocks
     constexpr int CPR = D / 8;   // 16-B chunks per row
-    constexpr int NLD = (KT * CPR) / 256;  // staging loads per thread per tensor
+    constexpr int NLD = (KT * CPR) / NT;  // staging loads per thread per tensor
+    static_assert(NLD >= 1, "tile too small for this workgroup size");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsK = smem;              // [2][TILEB]
@@ -108,32 +115,36 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_kernel(const FwdParams p) {
         }
     }
 
-    // ---- staging: each thread moves NLD 16-byte chunks of K and of V per tile
+    // ---- staging: each thread moves NLD 16-byte chunks of K and of V per tile.
+    // buffer loads: wave-uniform descriptor (per (b,h) base + Sk rows), per-thread byte offset fixed for the whole
+    // kernel, tile offset in an SGPR -> no per-tile vector address arithmetic, and rows >= Sk read back as zeros.
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase), 0, p.kbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase), 0, p.vbytes, 0x00020000);
+    unsigned kvoff[NLD], vvoff[NLD];
+    int ldsoff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int ci = tid + i * NT;
+        const int row = ci / CPR, ch = ci % CPR;
+        kvoff[i] = (unsigned)(row * (int)p.ks[2] * 2 + ch * 16);
+        vvoff[i] = (unsigned)(row * (int)p.vs[2] * 2 + ch * 16);
+        ldsoff[i] = tile_off<D>(row, ch);
+    }
+    const int ktile_bytes = KT * (int)p.ks[2] * 2;
+    const int vtile_bytes = KT * (int)p.vs[2] * 2;
     u32x4 stK[NLD], stV[NLD];
     auto stage_load = [&](int t) {
-        const int k0 = t * KT;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int ci = tid + i * 256;
-            const int row = ci / CPR, ch = ci % CPR;
-            const int key = k0 + row;
-            u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
-            if (key < p.Sk) {
-                zk = gload16(kbase + (int64_t)key * p.ks[2] * 2 + ch * 16);
-                zv = gload16(vbase + (int64_t)key * p.vs[2] * 2 + ch * 16);
-            }
-            stK[i] = zk;
-            stV[i] = zv;
+            stK[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i], t * ktile_bytes, 0);
+            stV[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i], t * vtile_bytes, 0);
         }
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int ci = tid + i * 256;
-            const int row = ci / CPR, ch = ci % CPR;
-            const int off = tile_off<D>(row, ch);
-            *LDS_PTR(u32x4, ldsK + buf * TILEB + off) = stK[i];
-            *LDS_PTR(u32x4, ldsV + buf * TILEB + off) = stV[i];
+            *LDS_PTR(u32x4, ldsK + buf * TILEB + ldsoff[i]) = stK[i];
+            *LDS_PTR(u32x4, ldsV + buf * TILEB + ldsoff[i]) = stV[i];
         }
     };
 
@@ -156,15 +167,22 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_kernel(const FwdParams p) {
         stage_store(0);
     }
     __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) retire_loads(qf[qb][s]);
+    // static priority for the second-dispatched half of an 8-wave workgroup (waves w and w+4 share a SIMD): the two
+    // co-resident waves stop running their matrix / exponential phases in lock step
+    if (PRIO && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(PRIO);
 
     // rows of this wave: [qw0, qw0 + QB*32)
     const int wave_first_vis = qw0 + coff;                 // last visible key of the wave's first row
     const int wave_last_vis = qw0 + QB * 32 - 1 + coff;    // last visible key of the wave's last row
 
     for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
+        const int buf = (ABL == 6 || ABL == 7) ? 0 : (t & 1);
         const int k0 = t * KT;
-        if (t + 1 < ntiles) stage_load(t + 1);
+        if (ABL != 6 && ABL != 7 && ABL != 8 && t + 1 < ntiles) stage_load(t + 1);
 
         // wave-uniform tile classification
         bool skip = false;       // no visible element for this wave
@@ -192,40 +210,51 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_kernel(const FwdParams p) {
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
+                    vec8 kf;
+                    if (ABL == 5 || ABL == 7) { kf = qf[0][s]; asm volatile("" : "+v"(kf)); }
+                    else kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
+                    for (int qb = 0; qb < QB; ++qb) {
+                        if (ABL == 2 || ABL == 4) {
+                            asm volatile("" : "+v"(kf));
+                            sacc[qb][kb][s] += 1.0f;
+                        } else {
+                            sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
+                        }
+                    }
                 }
             }
 
             // ---- online softmax_n per query block
+            // Fast path (no hidden element in the tile): exponentiate against the CURRENT running max without computing
+            // the tile max first; the result is exact as long as nothing overflows, which the row sum itself reveals
+            // (any p > 2^8, an unset max (-inf) or a NaN makes the lane's partial sum exceed kSumLimit / compare false).
+            // Only then - wave-uniformly - is the tile redone on the exact path, which re-centres the max.
             vec8 pf[QB][2][2];  // [qb][kb][t]: B operand of the PV MFMA
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                const int row = qw0 + qb * 32 + l31;
-                float alpha, m_new;
-                if (!need_mask) {
-                    // fast path: max on raw scores, scale folded into the exp2 argument (c > 0)
-                    float mx = sacc[qb][0][0];
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][kb][r]);
-                    mx = max_across_halves(mx);
-                    m_new = fmaxf(m_run[qb], mx * p.c);
-                    alpha = fast_exp2(m_run[qb] - m_new);
+                bool exact = need_mask;
+                if (!exact) {
                     float rs = 0.f;
+                    const float mneg = -m_run[qb];
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float pv = fast_exp2(__builtin_fmaf(sacc[qb][kb][r], p.c, -m_new));
-                            sacc[qb][kb][r] = pv;
-                            rs += pv;
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            f32x8 x;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                if (ABL == 1) x[e] = sacc[qb][kb][8 * t2 + e];
+                                else x[e] = fast_exp2(__builtin_fmaf(sacc[qb][kb][8 * t2 + e], p.c, mneg));
+                                rs += x[e];
+                            }
+                            pf[qb][kb][t2] = E::cvt8(x);
                         }
-                    l_run[qb] = l_run[qb] * alpha + rs;
-                } else {
-                    // element-wise path: y = s*c + bias*log2e, -inf where hidden
+                    if (ABL == 0 && __any(!(rs <= kSumLimit))) exact = true;
+                    else l_run[qb] += rs;
+                }
+                if (exact) {
+                    const int row = qw0 + qb * 32 + l31;
                     float mx = -INFINITY;
                     const int vis = causal ? (row + coff) : 0x7fffffff;  // last visible key of this row
 #pragma unroll
@@ -254,38 +283,31 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_kernel(const FwdParams p) {
                             mx = fmaxf(mx, y);
                         }
                     mx = max_across_halves(mx);
-                    m_new = fmaxf(m_run[qb], mx);
+                    const float m_new = fmaxf(m_run[qb], mx);
                     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully hidden so far
-                    alpha = fast_exp2(m_run[qb] - m_use);
+                    const float alpha = fast_exp2(m_run[qb] - m_use);
                     float rs = 0.f;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float pv = fast_exp2(sacc[qb][kb][r] - m_use);
-                            sacc[qb][kb][r] = pv;
-                            rs += pv;
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            f32x8 x;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                x[e] = fast_exp2(sacc[qb][kb][8 * t2 + e] - m_use);
+                                rs += x[e];
+                            }
+                            pf[qb][kb][t2] = E::cvt8(x);
                         }
                     l_run[qb] = l_run[qb] * alpha + rs;
-                }
-                m_run[qb] = m_new;
-                // rescale the accumulator only when some row's max moved (wave-uniform branch)
-                if (!__all(alpha == 1.0f)) {
+                    m_run[qb] = m_new;
+                    if (!__all(alpha == 1.0f)) {
 #pragma unroll
-                    for (int d = 0; d < DB; ++d)
+                        for (int d = 0; d < DB; ++d)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
-                }
-                // pack P^T to 16 bit: registers 8t..8t+7 of key block kb -> k-slots of PV step (kb,t)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int t2 = 0; t2 < 2; ++t2) {
-                        f32x8 x;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = sacc[qb][kb][8 * t2 + e];
-                        pf[qb][kb][t2] = E::cvt8(x);
+                            for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
                     }
+                }
             }
 
             // ---- O^T += V^T P^T
@@ -295,14 +317,25 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_kernel(const FwdParams p) {
                 for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                     for (int d = 0; d < DB; ++d) {
-                        vec8 vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, d, lane);
+                        vec8 vf;
+                        if (ABL == 5 || ABL == 7) { vf = qf[0][d]; asm volatile("" : "+v"(vf)); }
+                        else vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, d, lane);
 #pragma unroll
-                        for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
+                        for (int qb = 0; qb < QB; ++qb) {
+                            if (ABL == 3 || ABL == 4) {
+                                asm volatile("" : "+v"(vf), "+v"(pf[qb][kb][t2]));
+                                oacc[qb][d][kb * 2 + t2] += 1.0f;
+                            } else {
+                                oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
+                            }
+                        }
                     }
         }
 
-        if (t + 1 < ntiles) stage_store(buf ^ 1);
-        __syncthreads();
+        if (ABL != 6 && ABL != 7) {
+            if (ABL != 8 && t + 1 < ntiles) stage_store(buf ^ 1);
+            if (ABL != 9) __syncthreads();   // ABL 8: barrier only; ABL 9: staging only
+        }
     }
 
     // ---- epilogue: O = acc / l, LSE = ln2 * (m + log2 l)

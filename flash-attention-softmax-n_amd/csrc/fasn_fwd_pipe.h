@@ -1,0 +1,310 @@
+// fasn_fwd_pipe.h — software-pipelined forward (MODE_PLAIN / MODE_CAUSAL): same math and data layout as
+// fasn_fwd_kernel.h, but each loop iteration t issues, in ONE basic block,
+//     MFMA stream :  O^T += V(t-1)^T P(t-1)^T      and      S(t+1)^T = K(t+1) Q^T
+//     VALU stream :  P(t)^T = exp2(c*S(t)^T - m)   (optimistic softmax_n fast path, see fasn_fwd_kernel.h)
+// so a wave's own matrix instructions run under its own exponentials (an in-order wave overlaps an MFMA only with the
+// instructions that follow it in program order), instead of relying on a co-resident wave being in the other phase.
+// K runs two tiles ahead of V in the LDS ring: iteration t reads K(t+1) and V(t-1), writes K(t+2) and V(t), and has
+// the global loads of K(t+3) and V(t+1) in flight; one s_barrier per tile.
+#pragma once
+#include "fasn_fwd_kernel.h"
+
+namespace fasn {
+
+template <typename Tag, int D, int QB, int MODE, int OCC>
+__global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams p) {
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "masked / biased attention uses fasn_fwd_kernel");
+    using E = ET<Tag>;
+    using vec8 = typename E::vec8;
+    constexpr int NW = 4;
+    constexpr int BM = NW * QB * 32;
+    constexpr int ROWB = D * 2;
+    constexpr int TILEB = KT * ROWB;
+    constexpr int KS = D / 16;
+    constexpr int DB = D / 32;
+    constexpr int CPR = D / 8;
+    constexpr int NLD = (KT * CPR) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsK = smem;              // [2][TILEB]
+    char* const ldsV = smem + 2 * TILEB;  // [2][TILEB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+
+    int bh, qi;
+    block_to_work(blockIdx.x, p.B * p.H, p.nqblk, bh, qi);
+    constexpr bool causal = MODE == MODE_CAUSAL;
+    const int qblk = causal ? (p.nqblk - 1 - qi) : qi;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qblk * BM;
+    const int qw0 = q0 + wave * (QB * 32);
+
+    const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
+    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
+    const int coff = p.Sk - p.Sq;
+
+    int ntiles = (p.Sk + KT - 1) / KT;
+    if (causal) {
+        const int kmax = min(q0 + BM, p.Sq) - 1 + coff;
+        ntiles = min(ntiles, kmax < 0 ? 0 : (kmax / KT + 1));
+    }
+
+    vec8 qf[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int row = qw0 + qb * 32 + l31;
+        const bool ok = row < p.Sq;
+        const char* rp = qbase + (int64_t)row * p.qs[2] * 2 + hi * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 raw = {0u, 0u, 0u, 0u};
+            if (ok) raw = gload16(rp + s * 32);
+            __builtin_memcpy(&qf[qb][s], &raw, 16);
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase), 0, p.kbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase), 0, p.vbytes, 0x00020000);
+    unsigned kvoff[NLD], vvoff[NLD];
+    int ldsoff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int ci = tid + i * 256;
+        const int row = ci / CPR, ch = ci % CPR;
+        kvoff[i] = (unsigned)(row * (int)p.ks[2] * 2 + ch * 16);
+        vvoff[i] = (unsigned)(row * (int)p.vs[2] * 2 + ch * 16);
+        ldsoff[i] = tile_off<D>(row, ch);
+    }
+    const int ktile_bytes = KT * (int)p.ks[2] * 2;
+    const int vtile_bytes = KT * (int)p.vs[2] * 2;
+    u32x4 stK[NLD], stV[NLD];
+    auto loadK = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) stK[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i], t * ktile_bytes, 0);
+    };
+    auto loadV = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) stV[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i], t * vtile_bytes, 0);
+    };
+    auto storeK = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *LDS_PTR(u32x4, ldsK + buf * TILEB + ldsoff[i]) = stK[i];
+    };
+    auto storeV = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *LDS_PTR(u32x4, ldsV + buf * TILEB + ldsoff[i]) = stV[i];
+    };
+
+    float m_run[QB], l_run[QB];
+    f32x16 oacc[QB][DB];
+    f32x16 sacc[QB][2];
+    vec8 pf[QB][2][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const bool sink = p.n > 0.f;
+        m_run[qb] = sink ? 0.f : -INFINITY;
+        l_run[qb] = (sink && hi == 0) ? p.n : 0.f;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[qb][kb][t2][e] = 0;  // P(-1) = 0
+    }
+
+    auto qk_tile = [&](const char* tK, f32x16 (&s)[QB][2]) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, ks, hi);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) s[qb][kb] = E::mfma(kf, qf[qb][ks], s[qb][kb]);
+            }
+    };
+    auto pv_tile = [&](const char* tV) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    vec8 vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, d, lane);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
+                }
+    };
+
+    // ---- prologue: V(-1) := 0 in vbuf[1]; K(0) -> kbuf[0], K(1) -> kbuf[1]; S(0); K(2), V(0) in flight
+    if (ntiles > 0) {
+        loadK(0);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *LDS_PTR(u32x4, ldsV + TILEB + ldsoff[i]) = z;
+        }
+        storeK(0);
+        loadK(1);
+        storeK(1);
+        loadK(2);
+        loadV(0);
+        __syncthreads();
+        qk_tile(ldsK, sacc);
+        __syncthreads();  // every wave has read K(0) before K(2) replaces it
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) retire_loads(qf[qb][s]);
+    const int wave_first_vis = qw0 + coff;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * KT;
+        // the tiles loaded one iteration ago land in the buffers nobody reads during this iteration
+        storeK(t & 1);   // K(t+2)
+        storeV(t & 1);   // V(t)
+        loadK(t + 3);
+        loadV(t + 1);
+
+        bool need_mask = (k0 + KT > p.Sk);
+        if (causal) need_mask = need_mask || ((k0 + KT - 1) > wave_first_vis);
+
+        const char* tKn = ldsK + ((t + 1) & 1) * TILEB;   // K(t+1)
+        const char* tVp = ldsV + ((t + 1) & 1) * TILEB;   // V(t-1)  ((t-1)&1 == (t+1)&1)
+        f32x16 snext[QB][2];
+        vec8 pn[QB][2][2];
+        float lnew[QB];
+        bool bad = false;
+
+        if (!need_mask) {
+            // ---- ONE basic block: 16*QB MFMAs (PV of the previous tile, QK^T of the next) + the exponentials of this tile
+            pv_tile(tVp);
+            qk_tile(tKn, snext);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float rs = 0.f;
+                const float mneg = -m_run[qb];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        f32x8 x;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            x[e] = fast_exp2(__builtin_fmaf(sacc[qb][kb][8 * t2 + e], p.c, mneg));
+                            rs += x[e];
+                        }
+                        pn[qb][kb][t2] = E::cvt8(x);
+                    }
+                bad = bad || !(rs <= kSumLimit);
+                lnew[qb] = l_run[qb] + rs;
+            }
+        } else {
+            pv_tile(tVp);
+            qk_tile(tKn, snext);
+        }
+        if (need_mask || __any(bad)) {
+            // ---- exact path: tile max, re-centre, rescale (O already contains tile t-1, which used the old max)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const int row = qw0 + qb * 32 + l31;
+                const int vis = causal ? (row + coff) : 0x7fffffff;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        float y = sacc[qb][kb][r] * p.c;
+                        const bool show = (key < p.Sk) && (key <= vis);
+                        y = show ? y : -INFINITY;
+                        sacc[qb][kb][r] = y;
+                        mx = fmaxf(mx, y);
+                    }
+                mx = max_across_halves(mx);
+                const float m_new = fmaxf(m_run[qb], mx);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = fast_exp2(m_run[qb] - m_use);
+                float rs = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        f32x8 x;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            x[e] = fast_exp2(sacc[qb][kb][8 * t2 + e] - m_use);
+                            rs += x[e];
+                        }
+                        pn[qb][kb][t2] = E::cvt8(x);
+                    }
+                lnew[qb] = l_run[qb] * alpha + rs;
+                m_run[qb] = m_new;
+                if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                    for (int d = 0; d < DB; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
+                }
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            l_run[qb] = lnew[qb];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                sacc[qb][kb] = snext[qb][kb];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) pf[qb][kb][t2] = pn[qb][kb][t2];
+            }
+        }
+        __syncthreads();
+    }
+    if (ntiles > 0) pv_tile(ldsV + ((ntiles - 1) & 1) * TILEB);  // drain: O^T += V(last)^T P(last)^T
+
+    // ---- epilogue: O = acc / l, LSE = ln2 * (m + log2 l)
+    char* obase = p.o + (b * p.os[0] + h * p.os[1]) * 2;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int row = qw0 + qb * 32 + l31;
+        const float l_tot = sum_across_halves(l_run[qb]);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (row < p.Sq) {
+            if (p.lse != nullptr && hi == 0) {
+                const float m_use = (m_run[qb] == -INFINITY) ? 0.f : m_run[qb];
+                p.lse[(int64_t)bh * p.Sq + row] = l_tot > 0.f ? (m_use + __builtin_log2f(l_tot)) * kLn2 : -INFINITY;
+            }
+            char* rp = obase + (int64_t)row * p.os[2] * 2;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = oacc[qb][d][4 * g + e] * inv;
+                    typename E::vec4 y = E::cvt4(x);
+                    u32x2 raw;
+                    __builtin_memcpy(&raw, &y, 8);
+                    gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
+                }
+        }
+    }
+}
+
+}  // namespace fasn

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fasn_fwd_kernel.h"
+#include "fasn_fwd_pipe.h"
+#include "fasn_fwd_pp.h"
 
 namespace fasn {
 
@@ -34,6 +36,86 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
     const dim3 grid((unsigned)(p.nqblk * p.B * p.H));
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+template <typename Tag, int D, int QB, int MODE, int OCC>
+int launch_fwd_pipe_one(FwdParams p, hipStream_t s) {
+    constexpr int BM = 4 * QB * 32;
+    constexpr int smem = 4 * KT * D * 2;
+    p.nqblk = (p.Sq + BM - 1) / BM;
+    auto kern = fasn_fwd_pipe_kernel<Tag, D, QB, MODE, OCC>;
+    if (smem > 48 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+// developer ablation launcher (plain mode, 4 waves)
+template <typename Tag, int D, int QB, int OCC, int ABL>
+int launch_fwd_abl(FwdParams p, hipStream_t s) {
+    constexpr int BM = 4 * QB * 32;
+    constexpr int smem = 4 * KT * D * 2;
+    p.nqblk = (p.Sq + BM - 1) / BM;
+    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_PLAIN, OCC, 4, 0, ABL>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+// 8-wave workgroups of the plain kernel (QB 32-row blocks per wave), optional static priority for waves 4-7
+template <typename Tag, int D, int QB, int MODE, int OCC, int PRIO>
+int launch_fwd_w8_one(FwdParams p, hipStream_t s) {
+    constexpr int BM = 8 * QB * 32;
+    constexpr int smem = 4 * KT * D * 2;
+    p.nqblk = (p.Sq + BM - 1) / BM;
+    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, 8, PRIO>;
+    if (smem > 48 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(512), smem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+template <typename Tag, int D, int QB, int OCC, int PRIO>
+int launch_fwd_w8_mode(const FwdParams& p, int mode, hipStream_t s) {
+    if (mode == MODE_PLAIN) return launch_fwd_w8_one<Tag, D, QB, MODE_PLAIN, OCC, PRIO>(p, s);
+    return launch_fwd_w8_one<Tag, D, QB, MODE_CAUSAL, OCC, PRIO>(p, s);
+}
+
+template <typename Tag, int D, int MODE, int OCC>
+int launch_fwd_pp_one(FwdParams p, hipStream_t s) {
+    constexpr int BM = 256;
+    constexpr int smem = 4 * KT * D * 2;
+    p.nqblk = (p.Sq + BM - 1) / BM;
+    auto kern = fasn_fwd_pp_kernel<Tag, D, MODE, OCC>;
+    if (smem > 48 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(512), smem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+template <typename Tag, int D, int OCC>
+int launch_fwd_pp_mode(const FwdParams& p, int mode, hipStream_t s) {
+    if (mode == MODE_PLAIN) return launch_fwd_pp_one<Tag, D, MODE_PLAIN, OCC>(p, s);
+    return launch_fwd_pp_one<Tag, D, MODE_CAUSAL, OCC>(p, s);
+}
+
+// pipelined kernel for plain / causal; the general (mask / bias) mode stays on fasn_fwd_kernel
+template <typename Tag, int D, int QB, int OCC>
+int launch_fwd_pipe_mode(const FwdParams& p, int mode, hipStream_t s) {
+    if (mode == MODE_PLAIN) return launch_fwd_pipe_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
+    return launch_fwd_pipe_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
 }
 
 template <typename Tag, int D, int QB, int OCC>
