@@ -29,6 +29,7 @@ WORKLOADS = {
     "c2": (8, 16, 1024, 64, torch.bfloat16, 1.0, False),
     "c3": (8, 16, 4096, 64, torch.float16, 1.0, True),
     "c5": (64, 16, 4096, 64, torch.bfloat16, 1.0, True),
+    "c4": (4, 32, 8192, 128, torch.bfloat16, 0.5, False),   # + dense ALiBi bias [H,L,S] and key-padding mask [B,1,1,S]
 }
 PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak, MI355X (MI355X_MICROARCH.md)
 
@@ -65,8 +66,13 @@ def main():
     B, H, S, D, dtype, n, causal = WORKLOADS[args.workload]
     q, k, v = (synth.counter_normal((B, H, S, D), seed, dtype=dtype, device=dev) for seed in (101, 102, 103))
 
+    bias = mask = None
+    if args.workload == "c4":
+        bias = synth.alibi_bias(H, S, S, dtype, device=dev)
+        mask = synth.keypad_mask(B, S, device=dev)
+
     def step():
-        return pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal)
+        return pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal, attn_mask=mask, attn_bias=bias)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -91,7 +97,8 @@ def main():
     o2 = torch.empty_like(q)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
     a = pkg._lib.FwdArgs()
-    fa._fill_fwd(a, q, k, v, o2, lse, None, None, n, 1.0 / D ** 0.5, causal)
+    fa._fill_fwd(a, q, k, v, o2, lse, None if mask is None else mask.expand(B, H, S, S).view(torch.uint8),
+                 None if bias is None else bias.unsqueeze(0).expand(B, H, S, S), n, 1.0 / D ** 0.5, causal)
     ms = ctypes.c_float(0.0)
     stream = torch.cuda.current_stream().cuda_stream
     pkg._lib.check(pkg._lib.load().fasn_time_fwd(a, stream, 3, max(10, args.steps), ctypes.byref(ms)), "fasn_time_fwd")
@@ -133,14 +140,17 @@ def main():
         qc, kc, vc = (t[0:1, :hs].cpu() for t in (q, k, v))
         threads = torch.get_num_threads()
         t1 = time.perf_counter()
-        ref = ref_attention_n(qc, kc, vc, softmax_n_param=n, is_causal=causal)
+        bc = None if bias is None else bias[:hs].cpu()
+        mc = None if mask is None else mask[0:1].cpu()
+        ref = ref_attention_n(qc, kc, vc, softmax_n_param=n, is_causal=causal, attn_bias=bc, attn_mask=mc)
         cpu_dt = time.perf_counter() - t1
         frac = hs / (B * H)
         line["cpu_baseline"] = {"value": frac / cpu_dt, "unit": "attn-ops/s", "cores": threads, "kind": "port",
                                 "sample": f"batch 0, heads 0..{hs - 1} of the same inputs ({hs}/{B * H} of one op), {cpu_dt:.2f} s, "
                                           f"scaled linearly; oracle/ref_attention.py (eager {line['dtype']}, as slow_attention_n)"}
         line["max_abs_err"] = float((out[0:1, :hs].float().cpu() - ref.float()).abs().max())
-        ref32 = ref_attention_n(qc[:, :2].float(), kc[:, :2].float(), vc[:, :2].float(), softmax_n_param=n, is_causal=causal)
+        ref32 = ref_attention_n(qc[:, :2].float(), kc[:, :2].float(), vc[:, :2].float(), softmax_n_param=n, is_causal=causal,
+                                attn_bias=None if bc is None else bc[:2].float(), attn_mask=mc)
         line["max_abs_err_vs_fp32_oracle"] = float((out[0:1, :2].float().cpu() - ref32).abs().max())
     print(json.dumps(line), flush=True)
     if world > 1:

@@ -70,6 +70,31 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     p.nqblk = 0;
     p.causal = a->causal ? 1 : 0;
     p.bias_f32 = (a->bias.ptr && a->bias_dtype == FASN_BIAS_F32) ? 1 : 0;
+    p.bias_vec = 0;
+    p.mask_vec = 0;
+    p.batch_inner = 0;
+    if (a->bias.ptr) {
+        const int esz = p.bias_f32 ? 4 : 2;
+        const int al = 4 * esz;  // 4 keys per load
+        bool ok = a->bias.stride[3] == 1 && (reinterpret_cast<uintptr_t>(a->bias.ptr) % al) == 0;
+        for (int i = 0; i < 3; ++i) ok = ok && ((a->bias.stride[i] * esz) % al == 0);
+        p.bias_vec = (ok && !p.bias_f32 && a->scale > 0.f) ? 1 : 0;  // fp32 bias / scale 0 take the element-load path
+    }
+    if (a->mask.ptr) {
+        bool ok = a->mask.stride[3] == 1 && (reinterpret_cast<uintptr_t>(a->mask.ptr) % 4) == 0;
+        for (int i = 0; i < 3; ++i) ok = ok && (a->mask.stride[i] % 4 == 0);
+        p.mask_vec = ok ? 1 : 0;
+    }
+    if (a->bias.ptr && a->bias.stride[0] == 0 && a->B > 1) p.batch_inner = 1;
+    p.bias_bytes = p.mask_bytes = 0;
+    {   // per-(b,h) slice extents for the buffer descriptors of the vector path; slices of 2 GiB or more use the element path
+        const int64_t bb = a->bias.ptr ? ((int64_t)(a->Sq - 1) * a->bias.stride[2] + a->Sk) * 2 : 0;
+        const int64_t mb = a->mask.ptr ? ((int64_t)(a->Sq - 1) * a->mask.stride[2] + a->Sk) : 0;
+        if (bb >= (1ll << 31)) p.bias_vec = 0;
+        if (mb >= (1ll << 31)) p.mask_vec = 0;
+        p.bias_bytes = (unsigned)bb;
+        p.mask_bytes = (unsigned)mb;
+    }
     p.c = a->scale * kLog2e;
     {
         const int64_t kb = (int64_t)a->Sk * a->k.stride[2] * 2, vb = (int64_t)a->Sk * a->v.stride[2] * 2;
@@ -81,7 +106,12 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
 
     l.dtype = a->dtype;
     l.D = a->D;
-    l.mode = (a->mask.ptr || a->bias.ptr) ? MODE_GENERAL : (a->causal ? MODE_CAUSAL : MODE_PLAIN);
+    if (a->mask.ptr || a->bias.ptr) {
+        const bool vec = (!a->bias.ptr || p.bias_vec) && (!a->mask.ptr || p.mask_vec);
+        l.mode = !vec ? MODE_GENERAL_SLOW : (a->bias.ptr && a->mask.ptr) ? MODE_GENERAL : a->bias.ptr ? MODE_GENERAL_B : MODE_GENERAL_M;
+    } else {
+        l.mode = a->causal ? MODE_CAUSAL : MODE_PLAIN;
+    }
     l.variant = internal_variant();
     return FASN_OK;
 }

@@ -2,8 +2,17 @@
 #include "fasn_launch.h"
 namespace fasn {
 template <typename Tag>
+static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    switch (l.mode) {
+        case MODE_GENERAL: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, 1>(p, s);
+        case MODE_GENERAL_B: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_B, 1>(p, s);
+        case MODE_GENERAL_M: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_M, 1>(p, s);
+        default: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_SLOW, 1>(p, s);
+    }
+}
+template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
-    if (l.mode == MODE_GENERAL) return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, 1>(p, s);
+    if (l.mode >= MODE_GENERAL) return launch_gen<Tag>(p, l, s);
     return launch_fwd_mode<Tag, 32, 2, 2>(p, l.mode, s);
 }
 int launch_fwd_d32(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {

@@ -3,8 +3,18 @@
 #include "fasn_launch.h"
 namespace fasn {
 template <typename Tag>
+static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    switch (l.mode) {
+        case MODE_GENERAL: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2>(p, s);
+        case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_B, 2>(p, s);
+        case MODE_GENERAL_M: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_M, 2>(p, s);
+        default: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_SLOW, 1>(p, s);
+    }
+}
+template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
-    const bool gen = l.mode == MODE_GENERAL;
+    if (l.mode >= MODE_GENERAL) return launch_gen<Tag>(p, l, s);
+    const bool gen = false;  // general modes returned above
     int v = l.variant;
     if (v == 0) {
         // auto (what ABI callers get), measured on MI355X at (8,16,4096,64):
@@ -15,11 +25,11 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     }
     switch (v) {
         // ---- production tuning points
-        case 100: return gen ? launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 2, 2>(p, l.mode, s);
-        case 1: return gen ? launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);
+        case 100: return launch_fwd_mode<Tag, 64, 2, 2>(p, l.mode, s);
+        case 1: return launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);
         // ---- alternatives kept for A/B measurements (tools/fasn_harness bench ... <variant>)
-        case 2: return gen ? launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 2, 1>(p, l.mode, s);
-        case 3: return gen ? launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 1, 2>(p, l.mode, s);
+        case 2: return launch_fwd_mode<Tag, 64, 2, 1>(p, l.mode, s);
+        case 3: return launch_fwd_mode<Tag, 64, 1, 2>(p, l.mode, s);
         case 4: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 1, 2>(p, l.mode, s); break;
         case 6: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 2, 1>(p, l.mode, s); break;
         case 9: if (!gen) return launch_fwd_pp_mode<Tag, 64, 2>(p, l.mode, s); break;
@@ -35,7 +45,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 29: return launch_fwd_abl<Tag, 64, 2, 2, 9>(p, s);
         default: break;
     }
-    return gen ? launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 1>(p, s) : launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);
+    return launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);
 }
 int launch_fwd_d64(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     return l.dtype == 1 ? go<bf16_tag>(p, l, s) : go<f16_tag>(p, l, s);

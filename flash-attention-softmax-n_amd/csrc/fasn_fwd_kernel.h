@@ -20,11 +20,16 @@
 // QB 32-row blocks and reuses every K / V fragment it reads from LDS for all of them. K/V tiles of 64
 // keys are staged global -> registers -> swizzled LDS image, double buffered, one barrier per tile.
 #pragma once
+#include <type_traits>
 #include "fasn_common.h"
 
 namespace fasn {
 
-enum { MODE_PLAIN = 0, MODE_CAUSAL = 1, MODE_GENERAL = 2 };
+// MODE_GENERAL: mask and/or bias through 4-key vector (buffer) loads - needs key stride 1 and aligned rows (bias_vec /
+// mask_vec). MODE_GENERAL_SLOW: anything else (fp32 or unaligned bias, strided mask) through per-element loads.
+// The vector kernels are specialised at compile time on which operands exist (MODE_GENERAL_B / _M / _BM), so that every
+// load in the tile loop is unconditional and hipcc can emit counted s_waitcnt vmcnt(N) instead of draining the queue.
+enum { MODE_PLAIN = 0, MODE_CAUSAL = 1, MODE_GENERAL = 2 /* = bias + mask */, MODE_GENERAL_SLOW = 3, MODE_GENERAL_B = 4, MODE_GENERAL_M = 5 };
 
 struct FwdParams {
     const char* q;
@@ -40,7 +45,11 @@ struct FwdParams {
     int nqblk;      // query blocks per head
     int causal;
     int bias_f32;   // bias elements are fp32 (else same 16-bit type as q)
+    int bias_vec;   // bias key stride 1 and every row 8-byte (16-bit) / 16-byte (fp32) aligned: 4 keys per load
+    int mask_vec;   // mask key stride 1 and every row 4-byte aligned: 4 keys per load
+    int batch_inner;  // bias/mask broadcast over batch: schedule the batch innermost so a head's bias tile is reused from L2
     unsigned kbytes, vbytes;  // byte extent of one (b,h) K / V matrix: Sk * row_stride * 2 (buffer descriptor range)
+    unsigned bias_bytes, mask_bytes;  // byte extent of one (b,h) bias / mask slice: (Sq-1)*row_stride + Sk elements
     float c;        // scale * log2(e)
     float n;        // softmax_n
 };
@@ -77,7 +86,20 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int hi = lane >> 5;
 
     int bh, qi;
-    block_to_work(blockIdx.x, p.B * p.H, p.nqblk, bh, qi);
+    constexpr bool VEC = MODE == MODE_GENERAL || MODE == MODE_GENERAL_B || MODE == MODE_GENERAL_M;
+    constexpr bool SLOW = MODE == MODE_GENERAL_SLOW;
+    constexpr bool GEN = VEC || SLOW;
+    constexpr bool VBIAS = MODE == MODE_GENERAL || MODE == MODE_GENERAL_B;   // vector bias present (compile time)
+    constexpr bool VMASK = MODE == MODE_GENERAL || MODE == MODE_GENERAL_M;   // vector mask present (compile time)
+    if (GEN && p.batch_inner && (p.H & 7) == 0) {
+        // per XCD: (head, q-block, batch) with the batch fastest -> the B workgroups that read the same bias tile run together
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int bb = j % p.B, rest = j / p.B;
+        qi = rest % p.nqblk;
+        bh = bb * p.H + (rest / p.nqblk) * 8 + xcd;
+    } else {
+        block_to_work(blockIdx.x, p.B * p.H, p.nqblk, bh, qi);
+    }
     // causal: heaviest (last) query blocks first
     const int qblk = (MODE != MODE_PLAIN && p.causal) ? (p.nqblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
@@ -88,7 +110,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
     const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
 
-    const bool causal = (MODE == MODE_CAUSAL) || (MODE == MODE_GENERAL && p.causal);
+    const bool causal = (MODE == MODE_CAUSAL) || (GEN && p.causal);
     const int coff = p.Sk - p.Sq;  // key j visible to row i iff j <= i + coff
 
     // ---- number of K/V tiles this workgroup walks
@@ -162,9 +184,58 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
     }
 
+    // ---- general mode addressing
+    // VEC : per-(b,h) buffer descriptors (range = that head's [Sq x Sk] slice, so reads past Sk on the last row return 0
+    //       instead of faulting; reads past Sk elsewhere return in-range garbage that the visibility select discards) and
+    //       a per-lane byte offset of this lane's row + its 4*hi keys; 4 keys per load.
+    // SLOW: per-lane row pointers, one element per load.
+    __amdgpu_buffer_rsrc_t brs, mrs;
+    unsigned bvo[QB], mvo[QB];
+    const char* bptr[QB];
+    const uint8_t* mptr[QB];
+    const bool has_bias = VBIAS || (SLOW && p.bias != nullptr);
+    const bool has_mask = VMASK || (SLOW && p.mask != nullptr);
+    if (GEN) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int rowc = min(qw0 + qb * 32 + l31, p.Sq - 1);
+            if (VEC) {
+                bvo[qb] = (unsigned)((rowc * p.bs[2] + 4 * hi) * 2);
+                mvo[qb] = (unsigned)(rowc * p.ms[2] + 4 * hi);
+            } else {
+                const int esz = p.bias_f32 ? 4 : 2;
+                bptr[qb] = has_bias ? p.bias + (b * p.bs[0] + h * p.bs[1] + (int64_t)rowc * p.bs[2] + 4 * hi * p.bs[3]) * esz : nullptr;
+                mptr[qb] = has_mask ? p.mask + (b * p.ms[0] + h * p.ms[1] + (int64_t)rowc * p.ms[2] + 4 * hi * p.ms[3]) : nullptr;
+            }
+        }
+        if (VEC) {
+            const char* bb = has_bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
+            const char* mb = has_mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
+            brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bb), 0, has_bias ? p.bias_bytes : 0u, 0x00020000);
+            mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mb), 0, has_mask ? p.mask_bytes : 0u, 0x00020000);
+        }
+    }
+
+    // VEC, bias present: the bias is folded into the QK^T accumulator INITIAL value (S' = bias*log2e/c + q.k, y = c*S'),
+    // so the softmax below is the plain one and no bias register outlives the MFMAs. A lane's pieces for the NEXT tile
+    // are loaded while the PV MFMAs of the current tile run.
+    u32x2 braw[QB][2][4];
+    constexpr bool bias_fold = VBIAS;
+    const float binv = bias_fold ? kLog2e / p.c : 0.f;
+    auto bias_gload = [&](int t) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    braw[qb][kb][g] = __builtin_amdgcn_raw_buffer_load_b64(brs, bvo[qb] + (kb * 32 + 8 * g) * 2, t * (KT * 2), 0);
+    };
+
     if (ntiles > 0) {
         stage_load(0);
         stage_store(0);
+        if (bias_fold) bias_gload(0);
     }
     __syncthreads();
 #pragma unroll
@@ -182,7 +253,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = (ABL == 6 || ABL == 7) ? 0 : (t & 1);
         const int k0 = t * KT;
-        if (ABL != 6 && ABL != 7 && ABL != 8 && t + 1 < ntiles) stage_load(t + 1);
+        if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && t + 1 < ntiles) stage_load(t + 1);
 
         // wave-uniform tile classification
         bool skip = false;       // no visible element for this wave
@@ -192,20 +263,48 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             need_mask = (k0 + KT - 1) > wave_first_vis;
         }
         if (k0 + KT > p.Sk) need_mask = true;
-        if (MODE == MODE_GENERAL) need_mask = true;
 
+        // VEC: mask bytes of this lane's elements, 4 consecutive keys per load; SLOW: every tile takes the exact path
+        uint32_t mraw[QB][2][4];
+        constexpr bool bvec = VBIAS;            // this tile's bias sits in braw (loaded during the previous tile)
+        constexpr bool mvec = VMASK;
+        if (SLOW) need_mask = true;
+        if (mvec) {   // unconditional (also for skipped tiles) and ahead of the K/V prefetch: in-order vmcnt stays countable
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        mraw[qb][kb][g] = __builtin_amdgcn_raw_buffer_load_b32(mrs, mvo[qb] + kb * 32 + 8 * g, k0, 0);
+        }
+        if (VMASK) __builtin_amdgcn_sched_barrier(0);  // keep the mask loads OLDER than the K/V prefetch in the vmcnt queue
+        if (VEC) stage_load(t + 1);   // past-the-end tiles read back as zeros
+        if (VMASK) __builtin_amdgcn_sched_barrier(0);
         if (!skip) {
             const char* tK = ldsK + buf * TILEB;
             const char* tV = ldsV + buf * TILEB;
 
             // ---- S^T = K Q^T : acc[qb][kb], 32 keys x 32 queries each
             f32x16 sacc[QB][2];
+            if (bvec) {
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
+                for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = 0.f;
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
+                            sacc[qb][kb][r] = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * binv;
+                        }
+            } else {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = 0.f;
+            }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -237,48 +336,98 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 if (!exact) {
                     float rs = 0.f;
                     const float mneg = -m_run[qb];
+                    auto fast = [&](auto HM) {
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
+                        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                        for (int t2 = 0; t2 < 2; ++t2) {
-                            f32x8 x;
+                            for (int t2 = 0; t2 < 2; ++t2) {
+                                f32x8 x;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                if (ABL == 1) x[e] = sacc[qb][kb][8 * t2 + e];
-                                else x[e] = fast_exp2(__builtin_fmaf(sacc[qb][kb][8 * t2 + e], p.c, mneg));
-                                rs += x[e];
+                                for (int e = 0; e < 8; ++e) {
+                                    const int r = 8 * t2 + e, g = r >> 2, ee = r & 3;
+                                    const float t = __builtin_fmaf(sacc[qb][kb][r], p.c, mneg);
+                                    float pv;
+                                    if (ABL == 1) pv = sacc[qb][kb][r];
+                                    else pv = fast_exp2(t);
+                                    if (decltype(HM)::value) {
+                                        const uint32_t w = mraw[qb][kb][g];  // mask bytes are 0 / 1 (torch.bool)
+                                        const float mf = (float)((w >> (8 * ee)) & 0xffu);  // v_cvt_f32_ubyteN
+                                        pv *= mf;
+                                    }
+                                    x[e] = pv;
+                                    rs += pv;
+                                }
+                                pf[qb][kb][t2] = E::cvt8(x);
                             }
-                            pf[qb][kb][t2] = E::cvt8(x);
-                        }
+                    };
+                    using T_ = std::true_type;
+                    using F_ = std::false_type;
+                    if (VMASK) fast(T_{});
+                    else fast(F_{});
                     if (ABL == 0 && __any(!(rs <= kSumLimit))) exact = true;
                     else l_run[qb] += rs;
                 }
                 if (exact) {
                     const int row = qw0 + qb * 32 + l31;
-                    float mx = -INFINITY;
                     const int vis = causal ? (row + coff) : 0x7fffffff;  // last visible key of this row
+                    // (1) y = s*c, plus the additive bias (tile-uniform choice of load path: no per-element branching)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[qb][kb][r] *= p.c;
+                    if (SLOW && has_bias) {
+                        // fp32 / unaligned / strided bias: element loads, predicated on the key range
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int kofs = k0 + kb * 32 + (r & 3) + 8 * (r >> 2);  // + 4*hi is in bptr
+                                float bv = 0.f;
+                                if (kofs + 4 * hi < p.Sk) {
+                                    if (p.bias_f32) bv = reinterpret_cast<const float*>(bptr[qb])[(int64_t)kofs * p.bs[3]];
+                                    else bv = E::to_f32(reinterpret_cast<const uint16_t*>(bptr[qb])[(int64_t)kofs * p.bs[3]]);
+                                }
+                                sacc[qb][kb][r] = __builtin_fmaf(bv, kLog2e, sacc[qb][kb][r]);
+                            }
+                    }
+                    // (2) visibility bits of this lane's 32 elements: key range, causal limit, boolean mask
+                    uint32_t showbits = 0u;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            float y = sacc[qb][kb][r] * p.c;
-                            bool show = (key < p.Sk) && (key <= vis);
-                            if (MODE == MODE_GENERAL) {
-                                const bool inb = show && (row < p.Sq);
-                                if (p.bias != nullptr && inb) {
-                                    const int64_t bo = b * p.bs[0] + h * p.bs[1] + (int64_t)row * p.bs[2] + (int64_t)key * p.bs[3];
-                                    float bv;
-                                    if (p.bias_f32) bv = reinterpret_cast<const float*>(p.bias)[bo];
-                                    else bv = E::to_f32(reinterpret_cast<const uint16_t*>(p.bias)[bo]);
-                                    y = __builtin_fmaf(bv, kLog2e, y);
-                                }
-                                if (p.mask != nullptr && inb) {
-                                    const int64_t mo = b * p.ms[0] + h * p.ms[1] + (int64_t)row * p.ms[2] + (int64_t)key * p.ms[3];
-                                    show = p.mask[mo] != 0;
+                            if ((key < p.Sk) && (key <= vis)) showbits |= 1u << (kb * 16 + r);
+                        }
+                    if (mvec) {
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const uint32_t w = mraw[qb][kb][g];
+                                const uint32_t nz = ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) |
+                                                    ((w & 0xff000000u) ? 8u : 0u);
+                                showbits &= ~(0xfu << (kb * 16 + 4 * g)) | (nz << (kb * 16 + 4 * g));
+                            }
+                    }
+                    if (SLOW && has_mask) {
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int kofs = k0 + kb * 32 + (r & 3) + 8 * (r >> 2);
+                                if (kofs + 4 * hi < p.Sk) {
+                                    if (mptr[qb][(int64_t)kofs * p.ms[3]] == 0) showbits &= ~(1u << (kb * 16 + r));
                                 }
                             }
-                            y = show ? y : -INFINITY;
+                    }
+                    // (3) hide, row max
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float y = ((showbits >> (kb * 16 + r)) & 1u) ? sacc[qb][kb][r] : -INFINITY;
                             sacc[qb][kb][r] = y;
                             mx = fmaxf(mx, y);
                         }
@@ -310,6 +459,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 }
             }
 
+
             // ---- O^T += V^T P^T
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -332,8 +482,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     }
         }
 
+        if (bias_fold) bias_gload(t + 1);  // next tile's bias (past-the-end reads return 0); newest in the queue
         if (ABL != 6 && ABL != 7) {
-            if (ABL != 8 && t + 1 < ntiles) stage_store(buf ^ 1);
+            if (ABL != 8 && (VEC || t + 1 < ntiles)) stage_store(buf ^ 1);
             if (ABL != 9) __syncthreads();   // ABL 8: barrier only; ABL 9: staging only
         }
     }

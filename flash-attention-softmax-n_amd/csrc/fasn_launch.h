@@ -20,12 +20,12 @@ int launch_fwd_d64(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_fwd_d128(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 
 
-template <typename Tag, int D, int QB, int MODE, int OCC>
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4>
 int launch_fwd_one(FwdParams p, hipStream_t s) {
-    constexpr int BM = 4 * QB * 32;
+    constexpr int BM = NW * QB * 32;
     constexpr int smem = 4 * KT * D * 2;
     p.nqblk = (p.Sq + BM - 1) / BM;
-    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC>;
+    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW>;
     if (smem > 48 * 1024) {
         static bool done = false;  // benign race: idempotent attribute
         if (!done) {
@@ -34,7 +34,7 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
         }
     }
     const dim3 grid((unsigned)(p.nqblk * p.B * p.H));
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -123,7 +123,7 @@ int launch_fwd_mode(const FwdParams& p, int mode, hipStream_t s) {
     switch (mode) {
         case MODE_PLAIN: return launch_fwd_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
         case MODE_CAUSAL: return launch_fwd_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
-        default: return launch_fwd_one<Tag, D, QB, MODE_GENERAL, OCC>(p, s);
+        default: return -7;  // general (mask / bias) mode is dispatched explicitly by the per-D translation units
     }
 }
 

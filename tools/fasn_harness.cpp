@@ -460,13 +460,16 @@ static int do_test(int variant, bool quick) {
 
 static int do_bench(int argc, char** argv) {
     if (argc < 9) {
-        fprintf(stderr, "bench B H Sq Sk D dtype(0=f16,1=bf16) causal [variant] [iters] [bwd]\n");
+        fprintf(stderr, "bench B H Sq Sk D dtype(0=f16,1=bf16) causal [variant] [iters] [bwd] [n] [mask_kind] [bias_kind]\n");
         return 2;
     }
     Problem P = mk(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]), 1.f);
     const int variant = argc > 9 ? atoi(argv[9]) : 0;
     const int iters = argc > 10 ? atoi(argv[10]) : 20;
     const bool bwd = argc > 11 ? atoi(argv[11]) != 0 : false;
+    if (argc > 12) P.n = (float)atof(argv[12]);
+    if (argc > 13) P.mask_kind = atoi(argv[13]);
+    if (argc > 14) P.bias_kind = atoi(argv[14]);
     Host h;
     make_inputs(P, h, 3);
     Dev d;
