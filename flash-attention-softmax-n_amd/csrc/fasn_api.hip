@@ -37,7 +37,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0 || a->D <= 0 || a->Dv <= 0) return FASN_EINVAL;
     if (a->dtype != FASN_DTYPE_F16 && a->dtype != FASN_DTYPE_BF16) return FASN_EDTYPE;
     if (!fasn_supported(a->dtype, a->D, a->Dv)) return FASN_EHEADDIM;
-    if (a->dropout_p != 0.f) return FASN_EUNSUPPORTED;
+    if (!(a->dropout_p >= 0.f) || a->dropout_p >= 1.f) return FASN_EINVAL;
     if (!(a->softmax_n >= 0.f) || !(a->scale >= 0.f) || !isfinite(a->scale)) return FASN_EINVAL;
     int rc;
     if ((rc = check_view(a->q, true))) return rc;
@@ -95,6 +95,17 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
         p.bias_bytes = (unsigned)bb;
         p.mask_bytes = (unsigned)mb;
     }
+    // dropout: 8-bit threshold, drop probability thr/256 (the nearest representable value to dropout_p, at least 1/256)
+    p.drop_thr = 0;
+    p.drop_scale = 1.f;
+    if (a->dropout_p > 0.f) {
+        int thr = (int)lrintf(a->dropout_p * 256.f);
+        thr = thr < 1 ? 1 : (thr > 255 ? 255 : thr);
+        p.drop_thr = (unsigned)thr;
+        p.drop_scale = 256.f / (256.f - (float)thr);
+    }
+    p.seed_lo = (unsigned)(a->seed & 0xffffffffu) ^ (unsigned)(a->offset * 0x9E3779B1u);
+    p.seed_hi = (unsigned)(a->seed >> 32) + (unsigned)(a->offset >> 32);
     p.c = a->scale * kLog2e;
     {
         const int64_t kb = (int64_t)a->Sk * a->k.stride[2] * 2, vb = (int64_t)a->Sk * a->v.stride[2] * 2;
@@ -108,7 +119,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     l.D = a->D;
     if (a->mask.ptr || a->bias.ptr) {
         const bool vec = (!a->bias.ptr || p.bias_vec) && (!a->mask.ptr || p.mask_vec);
-        l.mode = !vec ? MODE_GENERAL_SLOW : (a->bias.ptr && a->mask.ptr) ? MODE_GENERAL : a->bias.ptr ? MODE_GENERAL_B : MODE_GENERAL_M;
+        l.mode = (!vec || p.drop_thr) ? MODE_GENERAL_SLOW : (a->bias.ptr && a->mask.ptr) ? MODE_GENERAL : a->bias.ptr ? MODE_GENERAL_B : MODE_GENERAL_M;
     } else {
         l.mode = a->causal ? MODE_CAUSAL : MODE_PLAIN;
     }
@@ -140,7 +151,7 @@ const char* fasn_strerror(int code) {
         case FASN_EALIGN: return "pointer or stride breaks the 16-byte row alignment rule";
         case FASN_ESTRIDE: return "feature (last-dim) stride must be 1";
         case FASN_ELAUNCH: return "kernel launch failed";
-        case FASN_EUNSUPPORTED: return "request not implemented in this build (dropout_p must be 0)";
+        case FASN_EUNSUPPORTED: return "request not implemented in this build";
         case FASN_EWORKSPACE: return "workspace missing or too small";
         default: return "unknown fasn error";
     }

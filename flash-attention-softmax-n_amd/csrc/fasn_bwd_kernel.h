@@ -257,7 +257,13 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                         }
                         float pv = fast_exp2(y - lse2[qb]);
                         pv = show ? pv : 0.f;
-                        sacc[qb][kb][r] = pv * (pacc[qb][kb][r] - dlt[qb]);
+                        float dp = pacc[qb][kb][r];
+                        if (p.drop_thr) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
+                            const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row);
+                            const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)((k0 + kb * 32 + 8 * (r >> 2) + 4 * hi) >> 2));
+                            dp = drop_keep(hsh, r & 3, p.drop_thr) ? dp * p.drop_scale : 0.f;
+                        }
+                        sacc[qb][kb][r] = pv * (dp - dlt[qb]);
                     }
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -511,8 +517,18 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                         }
                         float pv = fast_exp2(y - lr[r]);
                         pv = show ? pv : 0.f;
-                        sacc[kb][r] = pv;
-                        pacc[kb][r] = pv * (pacc[kb][r] - xr[r]);
+                        float dp = pacc[kb][r];
+                        float pd = pv;
+                        if (p.drop_thr) {   // lane = key here: one hash per element, byte (key & 3) of the (row, key>>2) hash
+                            const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row);
+                            const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)(key >> 2));
+                            const bool keep = ((hsh >> (8 * (key & 3))) & 0xffu) >= p.drop_thr;
+                            dp = keep ? dp * p.drop_scale : 0.f;
+                            pd = keep ? pv * p.drop_scale : 0.f;
+                        }
+                        sacc[kb][r] = pd;                     // dropped weights feed dV
+                        pacc[kb][r] = pv * (dp - xr[r]);      // dS uses the undropped P
                     }
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {

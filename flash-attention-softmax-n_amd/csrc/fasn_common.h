@@ -142,6 +142,25 @@ FASN_DEV void retire_loads(V& v) {
     asm volatile("" : "+v"(v));
 }
 
+// ---- dropout -------------------------------------------------------------------------------------------------------
+// Counter-based, layout-independent: the keep/drop decision of attention weight (bh, row i, key j) is byte (j & 3) of
+// a 32-bit hash of (seed, bh, i, j >> 2); the weight is kept iff byte >= thr (drop probability thr/256). Every kernel
+// (forward and both backward kernels, which hold the score tile in different register layouts) recomputes the same bits.
+// Mirror on the host: flash-attention-softmax-n_amd/dropout.py (used by the tests to build the explicit mask).
+FASN_DEV uint32_t drop_row_base(uint32_t seed_lo, uint32_t bh, uint32_t row) {
+    return (seed_lo ^ (bh * 0x9E3779B1u)) + row * 0x85EBCA77u;
+}
+FASN_DEV uint32_t drop_hash(uint32_t row_base, uint32_t seed_hi, uint32_t key_quad) {
+    uint32_t x = row_base ^ (key_quad * 0xC2B2AE3Du + seed_hi);
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+FASN_DEV bool drop_keep(uint32_t hash, int e, uint32_t thr) { return ((hash >> (8 * e)) & 0xffu) >= thr; }
+
 FASN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // global 16-byte load / store helpers (pointers are 16-B aligned by the host-side contract)

@@ -12,6 +12,7 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 }
 template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (p.drop_thr) return launch_fwd_drop<Tag, 128, 1, 1>(p, l.mode, s);
     if (l.mode >= MODE_GENERAL) return launch_gen<Tag>(p, l, s);
     if (l.variant == 1) return launch_fwd_mode<Tag, 128, 1, 1>(p, l.mode, s);
     return launch_fwd_mode<Tag, 128, 1, 2>(p, l.mode, s);

@@ -50,6 +50,9 @@ struct FwdParams {
     int batch_inner;  // bias/mask broadcast over batch: schedule the batch innermost so a head's bias tile is reused from L2
     unsigned kbytes, vbytes;  // byte extent of one (b,h) K / V matrix: Sk * row_stride * 2 (buffer descriptor range)
     unsigned bias_bytes, mask_bytes;  // byte extent of one (b,h) bias / mask slice: (Sq-1)*row_stride + Sk elements
+    unsigned drop_thr;        // dropout: drop an attention weight iff its hash byte < drop_thr (0 = no dropout)
+    unsigned seed_lo, seed_hi;
+    float drop_scale;         // 256 / (256 - drop_thr): applied to O (and to dP in the backward)
     float c;        // scale * log2(e)
     float n;        // softmax_n
 };
@@ -61,7 +64,8 @@ constexpr float kSumLimit = 256.0f;
 // ABL (developer ablation, never dispatched by the ABI): 1 = no exponentials (P := raw S), 2 = no QK^T MFMAs,
 // 3 = no PV MFMAs, 4 = neither MFMA group, 5 = no K/V LDS fragment reads, 6 = no staging and no barrier,
 // 7 = 5 + 6, 8 = barrier but no staging, 9 = staging but no barrier
-template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0>
+// DROP: attention-weight dropout compiled in (separate instantiations so the no-dropout kernels keep their registers).
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0>
 __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -324,6 +328,18 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 }
             }
 
+            // dropout of the 8 weights of (qb, kb, t2): keys k0 + kb*32 + 16*t2 + 4*hi + {0..3} and + 8 + {0..3}
+            auto drop8 = [&](f32x8& x, int qb, int kb, int t2) {
+                const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)(qw0 + qb * 32 + l31));
+                const uint32_t kq = (uint32_t)((k0 + kb * 32 + 16 * t2 + 4 * hi) >> 2);
+                const uint32_t h0 = drop_hash(rb, p.seed_hi, kq), h1 = drop_hash(rb, p.seed_hi, kq + 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = drop_keep(h0, e, p.drop_thr) ? x[e] : 0.f;
+                    x[4 + e] = drop_keep(h1, e, p.drop_thr) ? x[4 + e] : 0.f;
+                }
+            };
+
             // ---- online softmax_n per query block
             // Fast path (no hidden element in the tile): exponentiate against the CURRENT running max without computing
             // the tile max first; the result is exact as long as nothing overflows, which the row sum itself reveals
@@ -357,6 +373,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                                     x[e] = pv;
                                     rs += pv;
                                 }
+                                if (DROP) drop8(x, qb, kb, t2);   // the row sum keeps the undropped weights
                                 pf[qb][kb][t2] = E::cvt8(x);
                             }
                     };
@@ -370,6 +387,20 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 if (exact) {
                     const int row = qw0 + qb * 32 + l31;
                     const int vis = causal ? (row + coff) : 0x7fffffff;  // last visible key of this row
+                    float mx = -INFINITY;
+                    if (!GEN) {
+                        // plain / causal: hide by key range and the causal limit only
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                const bool show = (key < p.Sk) && (key <= vis);
+                                const float y = show ? sacc[qb][kb][r] * p.c : -INFINITY;
+                                sacc[qb][kb][r] = y;
+                                mx = fmaxf(mx, y);
+                            }
+                    } else {
                     // (1) y = s*c, plus the additive bias (tile-uniform choice of load path: no per-element branching)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
@@ -422,7 +453,6 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             }
                     }
                     // (3) hide, row max
-                    float mx = -INFINITY;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -431,6 +461,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             sacc[qb][kb][r] = y;
                             mx = fmaxf(mx, y);
                         }
+                    }
                     mx = max_across_halves(mx);
                     const float m_new = fmaxf(m_run[qb], mx);
                     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully hidden so far
@@ -446,6 +477,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                                 x[e] = fast_exp2(sacc[qb][kb][8 * t2 + e] - m_use);
                                 rs += x[e];
                             }
+                            if (DROP) drop8(x, qb, kb, t2);
                             pf[qb][kb][t2] = E::cvt8(x);
                         }
                     l_run[qb] = l_run[qb] * alpha + rs;
@@ -495,7 +527,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     for (int qb = 0; qb < QB; ++qb) {
         const int row = qw0 + qb * 32 + l31;
         const float l_tot = sum_across_halves(l_run[qb]);
-        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        const float inv = l_tot > 0.f ? (DROP ? p.drop_scale : 1.0f) / l_tot : 0.f;
         if (row < p.Sq) {
             if (p.lse != nullptr && hi == 0) {
                 const float m_use = (m_run[qb] == -INFINITY) ? 0.f : m_run[qb];

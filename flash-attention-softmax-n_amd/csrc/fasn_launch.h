@@ -118,6 +118,24 @@ int launch_fwd_pipe_mode(const FwdParams& p, int mode, hipStream_t s) {
     return launch_fwd_pipe_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
 }
 
+// dropout instantiations: plain, causal, and the element-load general kernel (any mask / bias combination)
+template <typename Tag, int D, int QB, int MODE, int OCC>
+int launch_fwd_drop_one(FwdParams p, hipStream_t s) {
+    constexpr int BM = 4 * QB * 32;
+    constexpr int smem = 4 * KT * D * 2;
+    p.nqblk = (p.Sq + BM - 1) / BM;
+    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, 4, 0, 0, 1>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+template <typename Tag, int D, int QB, int OCC>
+int launch_fwd_drop(const FwdParams& p, int mode, hipStream_t s) {
+    if (mode == MODE_PLAIN) return launch_fwd_drop_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
+    if (mode == MODE_CAUSAL) return launch_fwd_drop_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
+    return launch_fwd_drop_one<Tag, D, QB, MODE_GENERAL_SLOW, 1>(p, s);
+}
+
 template <typename Tag, int D, int QB, int OCC>
 int launch_fwd_mode(const FwdParams& p, int mode, hipStream_t s) {
     switch (mode) {

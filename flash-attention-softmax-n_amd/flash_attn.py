@@ -52,7 +52,7 @@ def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal):
+def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p=0.0, seed=0, offset=0):
     a.q, a.k, a.v, a.o = _view4(q), _view4(k), _view4(v), _view4(o)
     a.lse = lse.data_ptr()
     a.mask = _view4(mask)
@@ -68,26 +68,26 @@ def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal):
     a.scale = scale
     a.softmax_n = n
     a.causal = 1 if causal else 0
-    a.dropout_p = 0.0
-    a.seed = 0
-    a.offset = 0
+    a.dropout_p = dropout_p
+    a.seed = seed
+    a.offset = offset
 
 
 class _FlashAttentionSoftmaxN(torch.autograd.Function):
     """autograd glue; same role as _FlashAttentionN (flash_attn_triton.py:241-336)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, bias, n: float, scale: float, causal: bool):
+    def forward(ctx, q, k, v, mask, bias, n: float, scale: float, causal: bool, dropout_p: float = 0.0, seed: int = 0):
         lib = _lib.load()
         B, H, L, D = q.shape
         o = torch.empty((B, H, L, v.shape[3]), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
         a = FwdArgs()
-        _fill_fwd(a, q, k, v, o, lse, mask, bias, n, scale, causal)
+        _fill_fwd(a, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p, seed, 0)
         with torch.cuda.device(q.device):
             _lib.check(lib.fasn_fwd(a, _stream_ptr(q.device)), "fasn_fwd")
         ctx.save_for_backward(q, k, v, o, lse, mask, bias)
-        ctx.n, ctx.scale, ctx.causal = n, scale, causal
+        ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, ctx.seed = n, scale, causal, dropout_p, seed
         return o
 
     @staticmethod
@@ -103,14 +103,14 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         dv = torch.empty((B, H, S, v.shape[3]), dtype=q.dtype, device=q.device)
         delta = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
         a = BwdArgs()
-        _fill_fwd(a.fwd, q, k, v, o, lse, mask, bias, ctx.n, ctx.scale, ctx.causal)
+        _fill_fwd(a.fwd, q, k, v, o, lse, mask, bias, ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, ctx.seed, 0)
         a.dout, a.dq, a.dk, a.dv = _view4(dout), _view4(dq), _view4(dk), _view4(dv)
         a.delta = delta.data_ptr()
         a.workspace = None
         a.workspace_bytes = 0
         with torch.cuda.device(q.device):
             _lib.check(lib.fasn_bwd(a, _stream_ptr(q.device)), "fasn_bwd")
-        return dq, dk, dv, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None, None
 
 
 def _pad_feature(t: Tensor, d: int) -> Tensor:
@@ -125,8 +125,9 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
         raise NotImplementedError(f"dtype {query.dtype}: the gfx950 MFMA path supports torch.float16 and torch.bfloat16")
     if key.dtype != query.dtype or value.dtype != query.dtype:
         raise TypeError("query, key and value must share one dtype")
-    if dropout_p and dropout_p > 0.0:
-        raise NotImplementedError("dropout_p > 0 is not implemented in ABI v1 (SURVEY.md §8f rank 1)")
+    dropout_p = float(dropout_p or 0.0)
+    if not 0.0 <= dropout_p < 1.0:
+        raise ValueError("dropout_p must be in [0, 1)")
     if query.dim() != 4:
         raise ValueError("query must be [B, H, L, E]")
     n = 0.0 if n is None else float(n)
@@ -171,7 +172,13 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
             bias = bias.to(query.dtype)
         bias = bias.expand(B, H, L, S)
 
-    out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal))
+    seed = 0
+    if dropout_p > 0.0:
+        # one 63-bit seed per call from torch's CPU generator (honours torch.manual_seed); the kernels derive every
+        # keep/drop bit from (seed, b, h, row, key) — see dropout.py for the host mirror
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, seed)
+    _attention.last_seed = seed
     return out if Ev == dpad else out[..., :Ev]
 
 
@@ -193,7 +200,7 @@ def flash_attention_n(
     :param value: [B, H, S, Ev].
     :param softmax_n_param: n >= 0; real values allowed (the reference's SDPA path takes integers only).
     :param scale: multiplies q.k^T; default 1/sqrt(E).
-    :param dropout_p: must be 0 (not implemented yet).
+    :param dropout_p: attention-weight dropout, realised in 1/256 steps (dropout.effective_p); mask regenerated in backward.
     :param attn_mask: bool, 4-D, broadcastable to [B, H, L, S]; True = attend.
     :param attn_bias: additive bias [H, L, S] or broadcastable to [B, H, L, S] (e.g. ALiBi); not differentiated.
     :param is_causal: bottom-right aligned causal mask (key j visible to row i iff j <= i + S - L).

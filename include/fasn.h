@@ -81,8 +81,9 @@ typedef struct fasn_fwd_args {
     float scale;        /* multiplies q.k before bias (reference default 1/sqrt(D)) */
     float softmax_n;    /* n >= 0, real-valued */
     int32_t causal;     /* bottom-right aligned: key j visible to row i iff j <= i + Sk - Sq */
-    float dropout_p;    /* must be 0 in ABI v1 (FASN_EUNSUPPORTED otherwise) */
-    uint64_t seed, offset; /* reserved for in-kernel Philox dropout */
+    float dropout_p;    /* in [0,1): attention-weight dropout; realised as thr/256 with thr = round(256 p) in [1,255] */
+    uint64_t seed, offset; /* dropout stream: the keep bit of (b,h,row,key) is a pure function of (seed, offset, indices);
+                              pass the SAME values to fasn_bwd (see flash-attention-softmax-n_amd/dropout.py) */
 } fasn_fwd_args;
 
 /*

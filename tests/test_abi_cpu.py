@@ -64,7 +64,8 @@ def test_argument_validation_codes(pkg):
     assert lib.fasn_fwd(_args(pkg, B=0), None) == -1
     assert lib.fasn_fwd(_args(pkg, dtype=2), None) == -2
     assert lib.fasn_fwd(_args(pkg, D=96, Dv=96), None) == -3
-    assert lib.fasn_fwd(_args(pkg, dropout_p=0.1), None) == -7
+    assert lib.fasn_fwd(_args(pkg, dropout_p=1.0), None) == -1
+    assert lib.fasn_fwd(_args(pkg, dropout_p=-0.1), None) == -1
     assert lib.fasn_fwd(_args(pkg, softmax_n=-1.0), None) == -1
     a = _args(pkg)
     a.q.ptr = a.q.ptr + 2
@@ -125,3 +126,12 @@ def test_synth_is_index_addressable_and_deterministic(pkg):
     assert torch.allclose(s.alibi_slopes(8), torch.tensor([2.0 ** -(i + 1) for i in range(8)], dtype=torch.float64))
     m = s.keypad_mask(4, 64)
     assert m.shape == (4, 1, 1, 64) and m.sum(-1).flatten().tolist() == [64, 56, 48, 32]
+
+
+def test_dropout_host_mirror_statistics(pkg):
+    d = pkg.dropout
+    assert d.threshold(0.0) == 0 and d.threshold(0.2) == 51 and d.threshold(1e-4) == 1 and d.threshold(0.9999) == 255
+    keep = d.keep_mask(7, 0, 2, 2, 128, 256, 0.25)
+    assert keep.shape == (2, 2, 128, 256) and abs((1 - keep.mean()) - 0.25) < 0.01
+    assert (d.keep_mask(7, 0, 2, 2, 128, 256, 0.25) == keep).all() and (d.keep_mask(8, 0, 2, 2, 128, 256, 0.25) != keep).any()
+    assert d.keep_mask(7, 0, 1, 1, 4, 4, 0.0).all()

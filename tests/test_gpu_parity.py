@@ -261,10 +261,80 @@ def test_real_valued_n_and_signature_aliases(pkg, dev):
     d = pkg.slow_attention_n(q[0], k[0], v[0], attn_mask=fm, softmax_n_param=1.0)   # 3-D inputs + (L,S) float mask
     _check(d, ref_attention_n(q[0].cpu().float(), k[0].cpu().float(), v[0].cpu().float(), softmax_n_param=1.0, attn_bias=fm.cpu()),
            dtype, "slow float mask")
-    with pytest.raises(NotImplementedError):
-        pkg.flash_attention_n(q, k, v, dropout_p=0.2)
+    with pytest.raises(ValueError):
+        pkg.flash_attention_n(q, k, v, dropout_p=1.0)
     with pytest.raises(NotImplementedError):
         pkg.flash_attention_n(q.float(), k.float(), v.float())
+
+
+# ---------------------------------------------------------------- dropout
+def _oracle_dropout(q, k, v, do, keep, p_eff, **kw):
+    """attention with an EXPLICIT keep mask on the softmax_n weights (reference functional.py:92: dropout after softmax_n)"""
+    from oracle.ref_attention import additive_term, ref_softmax_n
+    qc, kc, vc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v))
+    L, S = qc.shape[-2], kc.shape[-2]
+    scale = kw.get("scale") or qc.shape[-1] ** -0.5
+    add = additive_term(L, S, mask=kw.get("attn_mask"), bias=kw.get("attn_bias"), causal=kw.get("is_causal", False),
+                        dtype=torch.float32, device="cpu", batch_shape=tuple(qc.shape[:-2]))
+    w = qc @ kc.transpose(-2, -1) * scale
+    if add is not None:
+        w = w + add
+    w = ref_softmax_n(w, n=kw.get("softmax_n_param"))
+    w = w * torch.from_numpy(keep).float() / (1.0 - p_eff)
+    o = w @ vc
+    o.backward(do.detach().cpu().float())
+    return o, qc.grad, kc.grad, vc.grad
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["plain", "causal", "bias+mask"])
+@pytest.mark.parametrize("D", [32, 64, 128])
+def test_dropout_matches_oracle_with_explicit_mask(pkg, dev, D, mode, dtype):
+    """reference: dropout(softmax_n(...)) @ v (functional.py:91-93, flash_attn.py:122). The kernels' keep bits are a pure
+    function of (seed, b, h, row, key), mirrored on the host by dropout.keep_mask, so parity is exact up to rounding."""
+    B, H, L, S, p = 2, 3, 200, 264, 0.2
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    kw = {"softmax_n_param": 1.0}
+    mask = bias = None
+    if mode == "causal":
+        kw["is_causal"] = True
+    if mode == "bias+mask":
+        gen = torch.Generator().manual_seed(3)
+        bias = torch.randn(H, L, S, generator=gen).to(dtype).to(dev)
+        mask = synth.keypad_mask(B, S, device=dev)
+    torch.manual_seed(1234)
+    out = pkg.flash_attention_n(q, k, v, dropout_p=p, attn_mask=mask, attn_bias=bias, **kw)
+    seed = pkg.flash_attn._attention.last_seed
+    out.backward(do)
+    keep = pkg.dropout.keep_mask(seed, 0, B, H, L, S, p)
+    p_eff = pkg.dropout.effective_p(p)
+    assert abs((1.0 - keep.mean()) - p_eff) < 0.01
+    o, dq, dk, dv = _oracle_dropout(q, k, v, do, keep, p_eff, attn_mask=None if mask is None else mask.cpu(),
+                                    attn_bias=None if bias is None else bias.float().cpu(), **kw)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"dropout/{mode}/{nm}")
+    # same seed -> same bits; different seed -> different output; p = 0 path untouched
+    torch.manual_seed(1234)
+    assert torch.equal(out, pkg.flash_attention_n(q, k, v, dropout_p=p, attn_mask=mask, attn_bias=bias, **kw))
+    assert not torch.equal(out, pkg.flash_attention_n(q, k, v, dropout_p=p, attn_mask=mask, attn_bias=bias, **kw))
+
+
+def test_dropout_reference_grid_is_finite_and_unbiased(pkg, dev):
+    """the reference's own dropout check (tests/gpu/core/test_flash_attn.py:26-27,41-44) only asks for finite sums; also
+    check E[dropout(w)] = w: averaging over seeds approaches the no-dropout output"""
+    dtype = torch.bfloat16
+    shape = (6, 1, 1024, 64)
+    q, k, v = (_rand(shape, dtype, dev, s).requires_grad_() for s in (1, 2, 3))
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1, dropout_p=0.2, is_causal=True)
+    out.backward(_rand(shape, dtype, dev, 4, std=1.0))
+    for t in (out, q.grad, k.grad, v.grad):
+        assert torch.isfinite(t).all() and isinstance(t.float().sum().item(), float)
+    base = pkg.flash_attention_n(q, k, v, softmax_n_param=1).float()
+    acc = torch.zeros_like(base)
+    for i in range(16):
+        acc += pkg.flash_attention_n(q, k, v, softmax_n_param=1, dropout_p=0.2).float()
+    assert (acc / 16 - base).abs().max().item() < 0.25 * base.abs().max().item() + 0.01
 
 
 # ---------------------------------------------------------------- size-independent properties at full BASELINE sizes
