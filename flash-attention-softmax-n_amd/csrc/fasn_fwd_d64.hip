@@ -18,11 +18,11 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     const bool gen = false;  // general modes returned above
     int v = l.variant;
     if (v == 0) {
-        // auto (what ABI callers get), measured on MI355X at (8,16,4096,64):
-        //   plain : QB=2, 2 waves/SIMD 882 TFLOP/s  vs QB=1, 3 waves/SIMD 835   -> QB=2 unless the grid would be too small
-        //   causal: QB=1, 3 waves/SIMD 639 TFLOP/s  vs QB=2 503 (finer diagonal, better tail balance)
+        // auto (what ABI callers get), measured on MI355X at (8,16,4096,64), 200 launches each:
+        //   plain : QB=2 / 2 waves per SIMD / two-set K/V ring  977 TFLOP/s  (single set 957, QB=1 / 3 waves 899-928)
+        //   causal: QB=1 / 3 waves per SIMD / ring             728 TFLOP/s  (QB=2 686: coarser diagonal, worse tail)
         const long blocks_qb2 = (long)((p.Sq + 255) / 256) * p.B * p.H;
-        v = (l.mode == MODE_PLAIN && blocks_qb2 >= 1024) ? 100 : 1;
+        v = (l.mode == MODE_PLAIN && blocks_qb2 >= 1024) ? 40 : 41;
     }
     switch (v) {
         // ---- production tuning points
@@ -31,6 +31,9 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         // ---- alternatives kept for A/B measurements (tools/fasn_harness bench ... <variant>)
         case 2: return launch_fwd_mode<Tag, 64, 2, 1>(p, l.mode, s);
         case 3: return launch_fwd_mode<Tag, 64, 1, 2>(p, l.mode, s);
+        case 40: return launch_fwd_ring<Tag, 64, 2, 2>(p, l.mode, s);
+        case 41: return launch_fwd_ring<Tag, 64, 1, 3>(p, l.mode, s);
+        case 42: return launch_fwd_ring<Tag, 64, 1, 2>(p, l.mode, s);
         case 4: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 1, 2>(p, l.mode, s); break;
         case 6: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 2, 1>(p, l.mode, s); break;
         case 9: if (!gen) return launch_fwd_pp_mode<Tag, 64, 2>(p, l.mode, s); break;

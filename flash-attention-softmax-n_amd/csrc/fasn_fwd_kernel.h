@@ -65,7 +65,10 @@ constexpr float kSumLimit = 256.0f;
 // 3 = no PV MFMAs, 4 = neither MFMA group, 5 = no K/V LDS fragment reads, 6 = no staging and no barrier,
 // 7 = 5 + 6, 8 = barrier but no staging, 9 = staging but no barrier
 // DROP: attention-weight dropout compiled in (separate instantiations so the no-dropout kernels keep their registers).
-template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0>
+// RING: 1 = two staging register sets, K/V tiles are loaded TWO tiles ahead (the loop body is instantiated twice with the
+// sets swapped). One tile of lead is about 1.2 us at D=64, less than a first-touch HBM miss under load; in-order vmcnt
+// makes any older outstanding load block the wait, so the extra lead has to come from a second register set.
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0, int RING = 0>
 __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -158,19 +161,23 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     }
     const int ktile_bytes = KT * (int)p.ks[2] * 2;
     const int vtile_bytes = KT * (int)p.vs[2] * 2;
-    u32x4 stK[NLD], stV[NLD];
-    auto stage_load = [&](int t) {
+    u32x4 stK[RING + 1][NLD], stV[RING + 1][NLD];
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, RING>;
+    auto stage_load = [&](int t, auto SET) {
+        constexpr int S_ = decltype(SET)::value;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            stK[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i], t * ktile_bytes, 0);
-            stV[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i], t * vtile_bytes, 0);
+            stK[S_][i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i], t * ktile_bytes, 0);
+            stV[S_][i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i], t * vtile_bytes, 0);
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, auto SET) {
+        constexpr int S_ = decltype(SET)::value;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            *LDS_PTR(u32x4, ldsK + buf * TILEB + ldsoff[i]) = stK[i];
-            *LDS_PTR(u32x4, ldsV + buf * TILEB + ldsoff[i]) = stV[i];
+            *LDS_PTR(u32x4, ldsK + buf * TILEB + ldsoff[i]) = stK[S_][i];
+            *LDS_PTR(u32x4, ldsV + buf * TILEB + ldsoff[i]) = stV[S_][i];
         }
     };
 
@@ -237,8 +244,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     };
 
     if (ntiles > 0) {
-        stage_load(0);
-        stage_store(0);
+        stage_load(0, Set0{});
+        stage_store(0, Set0{});
+        if (RING) stage_load(1, Set1{});   // tile 1 in flight in the second set
         if (bias_fold) bias_gload(0);
     }
     __syncthreads();
@@ -254,10 +262,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int wave_first_vis = qw0 + coff;                 // last visible key of the wave's first row
     const int wave_last_vis = qw0 + QB * 32 - 1 + coff;    // last visible key of the wave's last row
 
-    for (int t = 0; t < ntiles; ++t) {
+    // one K/V tile; LSET = register set that receives the prefetch issued here, SSET = set written to LDS at the end
+    auto tile_body = [&](const int t, auto LSET, auto SSET) {
         const int buf = (ABL == 6 || ABL == 7) ? 0 : (t & 1);
         const int k0 = t * KT;
-        if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && t + 1 < ntiles) stage_load(t + 1);
+        if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
 
         // wave-uniform tile classification
         bool skip = false;       // no visible element for this wave
@@ -283,7 +292,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                         mraw[qb][kb][g] = __builtin_amdgcn_raw_buffer_load_b32(mrs, mvo[qb] + kb * 32 + 8 * g, k0, 0);
         }
         if (VMASK) __builtin_amdgcn_sched_barrier(0);  // keep the mask loads OLDER than the K/V prefetch in the vmcnt queue
-        if (VEC) stage_load(t + 1);   // past-the-end tiles read back as zeros
+        if (VEC) stage_load(t + 1 + RING, LSET);   // past-the-end tiles read back as zeros
         if (VMASK) __builtin_amdgcn_sched_barrier(0);
         if (!skip) {
             const char* tK = ldsK + buf * TILEB;
@@ -516,9 +525,17 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 
         if (bias_fold) bias_gload(t + 1);  // next tile's bias (past-the-end reads return 0); newest in the queue
         if (ABL != 6 && ABL != 7) {
-            if (ABL != 8 && (VEC || t + 1 < ntiles)) stage_store(buf ^ 1);
+            if (ABL != 8 && (VEC || RING || t + 1 < ntiles)) stage_store(buf ^ 1, SSET);
             if (ABL != 9) __syncthreads();   // ABL 8: barrier only; ABL 9: staging only
         }
+    };
+    if (RING) {
+        for (int t = 0; t < ntiles; t += 2) {
+            tile_body(t, Set0{}, Set1{});       // even tile: tile t+1 sits in set 1, tile t+2 goes to set 0
+            if (t + 1 < ntiles) tile_body(t + 1, Set1{}, Set0{});
+        }
+    } else {
+        for (int t = 0; t < ntiles; ++t) tile_body(t, Set0{}, Set0{});
     }
 
     // ---- epilogue: O = acc / l, LSE = ln2 * (m + log2 l)
