@@ -205,6 +205,12 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
     p.dv = (char*)a->dv.ptr;
     p.delta = a->delta;
     p.scale = a->fwd.scale;
+    {
+        const int64_t qb = (int64_t)a->fwd.Sq * a->fwd.q.stride[2] * 2, db = (int64_t)a->fwd.Sq * a->dout.stride[2] * 2;
+        if (qb <= 0 || db <= 0 || qb >= (1ll << 31) || db >= (1ll << 31)) return FASN_EINVAL;
+        p.qbytes = (unsigned)qb;
+        p.dobytes = (unsigned)db;
+    }
     for (int i = 0; i < 3; ++i) {
         p.dos[i] = a->dout.stride[i];
         p.dqs[i] = a->dq.stride[i];

@@ -31,6 +31,7 @@ struct BwdParams {
     float* delta;
     int64_t dos[3], dqs[3], dks[3], dvs[3];
     float scale;
+    unsigned qbytes, dobytes;  // byte extent of one (b,h) Q / dO matrix (buffer descriptor range)
     int nblk;  // blocks per head of the launching kernel
 };
 
@@ -64,34 +65,37 @@ __global__ void __launch_bounds__(256) fasn_bwd_delta_kernel(const BwdParams p) 
     if (gr < rows && sub == 0) p.delta[gr] = acc;
 }
 
-// shared helper: stage a [64][D] tile (rows row0..row0+63 of a [S][D] matrix) into registers / LDS
+// shared helpers: stage a [64][D] tile (rows row0..row0+63 of one (b,h) matrix) global -> registers -> swizzled LDS image.
+// Buffer loads through a per-(b,h) descriptor: fixed per-thread byte offset, tile offset in an SGPR, rows past the end of
+// the matrix read back as zeros (no predication, no per-tile vector address arithmetic).
 template <int D, int NLD>
-FASN_DEV void tile_gload(u32x4 (&st)[NLD], const char* base, int64_t row_stride, int row0, int nrows_total, int tid) {
-    constexpr int CPR = D / 8;
+struct TileStage {
+    unsigned voff[NLD];
+    int loff[NLD];
+    FASN_DEV void init(int tid, int64_t row_stride) {
+        constexpr int CPR = D / 8;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int ci = tid + i * 256;
-        const int row = ci / CPR, ch = ci % CPR;
-        const int gr = row0 + row;
-        u32x4 z = {0u, 0u, 0u, 0u};
-        if (gr < nrows_total) z = gload16(base + (int64_t)gr * row_stride * 2 + ch * 16);
-        st[i] = z;
+        for (int i = 0; i < NLD; ++i) {
+            const int ci = tid + i * 256;
+            const int row = ci / CPR, ch = ci % CPR;
+            voff[i] = (unsigned)(row * (int)row_stride * 2 + ch * 16);
+            loff[i] = tile_off<D>(row, ch);
+        }
     }
-}
-template <int D, int NLD>
-FASN_DEV void tile_lstore(const u32x4 (&st)[NLD], char* tile, int tid) {
-    constexpr int CPR = D / 8;
+    FASN_DEV void gload(u32x4 (&st)[NLD], __amdgpu_buffer_rsrc_t rs, int row0, int64_t row_stride) const {
+        const int soff = row0 * (int)row_stride * 2;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int ci = tid + i * 256;
-        const int row = ci / CPR, ch = ci % CPR;
-        *LDS_PTR(u32x4, tile + tile_off<D>(row, ch)) = st[i];
+        for (int i = 0; i < NLD; ++i) st[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], soff, 0);
     }
-}
+    FASN_DEV void lstore(const u32x4 (&st)[NLD], char* tile) const {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *LDS_PTR(u32x4, tile + loff[i]) = st[i];
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // dQ: workgroup = 4 waves x QB x 32 query rows, loop over 64-key tiles.
-template <typename Tag, int D, int QB, int MODE, int OCC>
+template <typename Tag, int D, int QB, int MODE, int OCC, int DROP = 0>
 __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams bp) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -164,11 +168,16 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
             for (int r = 0; r < 16; ++r) dqacc[qb][d][r] = 0.f;
 
     u32x4 stK[NLD], stV[NLD];
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase), 0, p.kbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase), 0, p.vbytes, 0x00020000);
+    TileStage<D, NLD> tsK, tsV;
+    tsK.init(tid, p.ks[2]);
+    tsV.init(tid, p.vs[2]);
     if (ntiles > 0) {
-        tile_gload<D, NLD>(stK, kbase, p.ks[2], 0, p.Sk, tid);
-        tile_gload<D, NLD>(stV, vbase, p.vs[2], 0, p.Sk, tid);
-        tile_lstore<D, NLD>(stK, ldsK, tid);
-        tile_lstore<D, NLD>(stV, ldsV, tid);
+        tsK.gload(stK, krs, 0, p.ks[2]);
+        tsV.gload(stV, vrs, 0, p.vs[2]);
+        tsK.lstore(stK, ldsK);
+        tsV.lstore(stV, ldsV);
     }
     __syncthreads();
 #pragma unroll
@@ -189,8 +198,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         const int buf = t & 1;
         const int k0 = t * KT;
         if (t + 1 < ntiles) {
-            tile_gload<D, NLD>(stK, kbase, p.ks[2], k0 + KT, p.Sk, tid);
-            tile_gload<D, NLD>(stV, vbase, p.vs[2], k0 + KT, p.Sk, tid);
+            tsK.gload(stK, krs, k0 + KT, p.ks[2]);
+            tsV.gload(stV, vrs, k0 + KT, p.vs[2]);
         }
         bool skip = false, need_mask = false;
         if (causal) {
@@ -231,13 +240,14 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
             for (int qb = 0; qb < QB; ++qb) {
                 const int row = qw0 + qb * 32 + l31;
                 const int vis = causal ? (row + coff) : 0x7fffffff;
+                auto elems = [&](auto MASKED) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float y = sacc[qb][kb][r] * p.c;
                         bool show = true;
-                        if (need_mask) {
+                        if (decltype(MASKED)::value) {
                             const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                             show = (key < p.Sk) && (key <= vis);
                             if (MODE == MODE_GENERAL) {
@@ -255,16 +265,19 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                                 }
                             }
                         }
-                        float pv = fast_exp2(y - lse2[qb]);
-                        pv = show ? pv : 0.f;
+                        float pv = (MODE == MODE_GENERAL) ? fast_exp2(y - lse2[qb]) : fast_exp2(__builtin_fmaf(sacc[qb][kb][r], p.c, -lse2[qb]));
+                        if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                         float dp = pacc[qb][kb][r];
-                        if (p.drop_thr) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
+                        if (DROP) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
                             const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row);
                             const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)((k0 + kb * 32 + 8 * (r >> 2) + 4 * hi) >> 2));
                             dp = drop_keep(hsh, r & 3, p.drop_thr) ? dp * p.drop_scale : 0.f;
                         }
                         sacc[qb][kb][r] = pv * (dp - dlt[qb]);
                     }
+                };
+                if (need_mask) elems(std::true_type{});
+                else elems(std::false_type{});
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -288,8 +301,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                     }
         }
         if (t + 1 < ntiles) {
-            tile_lstore<D, NLD>(stK, ldsK + (buf ^ 1) * TILEB, tid);
-            tile_lstore<D, NLD>(stV, ldsV + (buf ^ 1) * TILEB, tid);
+            tsK.lstore(stK, ldsK + (buf ^ 1) * TILEB);
+            tsV.lstore(stV, ldsV + (buf ^ 1) * TILEB);
         }
         __syncthreads();
     }
@@ -320,7 +333,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 // dK, dV: workgroup = 4 waves x KB x 32 keys, loop over 64-row Q/dO tiles.
 constexpr int QT = 64;  // query rows per tile
 
-template <typename Tag, int D, int KB, int MODE, int OCC>
+template <typename Tag, int D, int KB, int MODE, int OCC, int DROP = 0>
 __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams bp) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -397,6 +410,11 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             }
 
     u32x4 stQ[NLD], stD[NLD];
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qbase), 0, bp.qbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dobase), 0, bp.dobytes, 0x00020000);
+    TileStage<D, NLD> tsQ, tsD;
+    tsQ.init(tid, p.qs[2]);
+    tsD.init(tid, bp.dos[2]);
     float stL = 0.f, stX = 0.f;
     auto stats_gload = [&](int row0) {
         if (tid < QT) {
@@ -418,11 +436,11 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     };
 
     if (tq0 < ntq) {
-        tile_gload<D, NLD>(stQ, qbase, p.qs[2], tq0 * QT, p.Sq, tid);
-        tile_gload<D, NLD>(stD, dobase, bp.dos[2], tq0 * QT, p.Sq, tid);
+        tsQ.gload(stQ, qrs, tq0 * QT, p.qs[2]);
+        tsD.gload(stD, drs, tq0 * QT, bp.dos[2]);
         stats_gload(tq0 * QT);
-        tile_lstore<D, NLD>(stQ, ldsQ, tid);
-        tile_lstore<D, NLD>(stD, ldsDO, tid);
+        tsQ.lstore(stQ, ldsQ);
+        tsD.lstore(stD, ldsDO);
         stats_lstore(0);
     }
     __syncthreads();
@@ -438,8 +456,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         const int buf = (tq - tq0) & 1;
         const int r0 = tq * QT;
         if (tq + 1 < ntq) {
-            tile_gload<D, NLD>(stQ, qbase, p.qs[2], r0 + QT, p.Sq, tid);
-            tile_gload<D, NLD>(stD, dobase, bp.dos[2], r0 + QT, p.Sq, tid);
+            tsQ.gload(stQ, qrs, r0 + QT, p.qs[2]);
+            tsD.gload(stD, drs, r0 + QT, bp.dos[2]);
             stats_gload(r0 + QT);
         }
         const char* tQ = ldsQ + buf * TILEB;
@@ -494,11 +512,12 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
                     const int key = kw0 + kb * 32 + l31;
+                    auto elems = [&](auto MASKED) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float y = sacc[kb][r] * p.c;
                         bool show = true;
-                        if (need_mask) {
+                        if (decltype(MASKED)::value) {
                             const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                             show = (key < p.Sk) && (row < p.Sq) && (!causal || key <= row + coff);
                             if (MODE == MODE_GENERAL) {
@@ -515,11 +534,11 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                                 }
                             }
                         }
-                        float pv = fast_exp2(y - lr[r]);
-                        pv = show ? pv : 0.f;
+                        float pv = (MODE == MODE_GENERAL) ? fast_exp2(y - lr[r]) : fast_exp2(__builtin_fmaf(sacc[kb][r], p.c, -lr[r]));
+                        if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                         float dp = pacc[kb][r];
                         float pd = pv;
-                        if (p.drop_thr) {   // lane = key here: one hash per element, byte (key & 3) of the (row, key>>2) hash
+                        if (DROP) {   // lane = key here: one hash per element, byte (key & 3) of the (row, key>>2) hash
                             const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                             const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row);
                             const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)(key >> 2));
@@ -530,6 +549,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                         sacc[kb][r] = pd;                     // dropped weights feed dV
                         pacc[kb][r] = pv * (dp - xr[r]);      // dS uses the undropped P
                     }
+                    };
+                    if (need_mask) elems(std::true_type{});
+                    else elems(std::false_type{});
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {
                         f32x8 x, y;
@@ -558,8 +580,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             }
         }
         if (tq + 1 < ntq) {
-            tile_lstore<D, NLD>(stQ, ldsQ + (buf ^ 1) * TILEB, tid);
-            tile_lstore<D, NLD>(stD, ldsDO + (buf ^ 1) * TILEB, tid);
+            tsQ.lstore(stQ, ldsQ + (buf ^ 1) * TILEB);
+            tsD.lstore(stD, ldsDO + (buf ^ 1) * TILEB);
             stats_lstore(buf ^ 1);
         }
         __syncthreads();

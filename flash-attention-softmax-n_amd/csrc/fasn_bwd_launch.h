@@ -16,7 +16,7 @@ inline void set_smem(K kern, int smem) {
     if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
-template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K>
+template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, int DROP = 0>
 int launch_bwd_one(BwdParams p, hipStream_t s) {
     const int nbh = p.f.B * p.f.H;
     {   // delta
@@ -28,7 +28,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         constexpr int BM = 4 * QB * 32;
         constexpr int smem = 4 * KT * D * 2;
         p.nblk = (p.f.Sq + BM - 1) / BM;
-        auto kern = fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q>;
+        auto kern = fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q, DROP>;
         set_smem(kern, smem);
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
     }
@@ -36,7 +36,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         constexpr int BN = 4 * KB * 32;
         constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4;
         p.nblk = (p.f.Sk + BN - 1) / BN;
-        auto kern = fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K>;
+        auto kern = fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP>;
         set_smem(kern, smem);
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
     }
@@ -45,6 +45,13 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
 
 template <typename Tag, int D, int QB, int KB, int OCC_Q, int OCC_K>
 int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
+    if (p.f.drop_thr) {   // dropout: separate instantiations (the keep-bit hash costs registers the p = 0 kernels keep)
+        switch (mode) {
+            case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K, 1>(p, s);
+            case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K, 1>(p, s);
+            default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, 1, 1, 1>(p, s);
+        }
+    }
     switch (mode) {
         case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K>(p, s);
         case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K>(p, s);
