@@ -102,8 +102,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
 
     float m_run[QB], l_run[QB];
     f32x16 oacc[QB][DB];
-    f32x16 sacc[QB][2];
-    vec8 pf[QB][2][2];
+    // two register sets, alternating per tile: set c = t&1 holds S(t) (input of this iteration) and receives P(t);
+    // set c^1 holds P(t-1) (input) and receives S(t+1): no register copies between iterations
+    f32x16 sacc[2][QB][2];
+    vec8 pf[2][QB][2][2];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const bool sink = p.n > 0.f;
@@ -118,10 +120,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[qb][kb][t2][e] = 0;  // P(-1) = 0
+                for (int e = 0; e < 8; ++e) pf[1][qb][kb][t2][e] = 0;  // P(-1) = 0 lives in set 1 (tile 0 uses set 0)
     }
 
-    auto qk_tile = [&](const char* tK, f32x16 (&s)[QB][2]) {
+    auto qk_tile = [&](const char* tK, f32x16 (&s)[QB][2]) {  // s := K Q^T
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
                 for (int qb = 0; qb < QB; ++qb) s[qb][kb] = E::mfma(kf, qf[qb][ks], s[qb][kb]);
             }
     };
-    auto pv_tile = [&](const char* tV) {
+    auto pv_tile = [&](const char* tV, const vec8 (&pfx)[QB][2][2]) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
                 for (int d = 0; d < DB; ++d) {
                     vec8 vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, d, lane);
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
+                    for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vf, pfx[qb][kb][t2], oacc[qb][d]);
                 }
     };
 
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
         loadK(2);
         loadV(0);
         __syncthreads();
-        qk_tile(ldsK, sacc);
+        qk_tile(ldsK, sacc[0]);
         __syncthreads();  // every wave has read K(0) before K(2) replaces it
     }
 
@@ -174,7 +176,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
         for (int s = 0; s < KS; ++s) retire_loads(qf[qb][s]);
     const int wave_first_vis = qw0 + coff;
 
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile_body = [&](const int t, auto CSET) {
+        constexpr int C = decltype(CSET)::value;
         const int k0 = t * KT;
         // the tiles loaded one iteration ago land in the buffers nobody reads during this iteration
         storeK(t & 1);   // K(t+2)
@@ -187,15 +190,13 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
 
         const char* tKn = ldsK + ((t + 1) & 1) * TILEB;   // K(t+1)
         const char* tVp = ldsV + ((t + 1) & 1) * TILEB;   // V(t-1)  ((t-1)&1 == (t+1)&1)
-        f32x16 snext[QB][2];
-        vec8 pn[QB][2][2];
         float lnew[QB];
         bool bad = false;
 
         if (!need_mask) {
             // ---- ONE basic block: 16*QB MFMAs (PV of the previous tile, QK^T of the next) + the exponentials of this tile
-            pv_tile(tVp);
-            qk_tile(tKn, snext);
+            pv_tile(tVp, pf[C ^ 1]);
+            qk_tile(tKn, sacc[C ^ 1]);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 float rs = 0.f;
@@ -207,17 +208,17 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
                         f32x8 x;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            x[e] = fast_exp2(__builtin_fmaf(sacc[qb][kb][8 * t2 + e], p.c, mneg));
+                            x[e] = fast_exp2(__builtin_fmaf(sacc[C][qb][kb][8 * t2 + e], p.c, mneg));
                             rs += x[e];
                         }
-                        pn[qb][kb][t2] = E::cvt8(x);
+                        pf[C][qb][kb][t2] = E::cvt8(x);
                     }
                 bad = bad || !(rs <= kSumLimit);
                 lnew[qb] = l_run[qb] + rs;
             }
         } else {
-            pv_tile(tVp);
-            qk_tile(tKn, snext);
+            pv_tile(tVp, pf[C ^ 1]);
+            qk_tile(tKn, sacc[C ^ 1]);
         }
         if (need_mask || __any(bad)) {
             // ---- exact path: tile max, re-centre, rescale (O already contains tile t-1, which used the old max)
@@ -231,10 +232,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        float y = sacc[qb][kb][r] * p.c;
+                        float y = sacc[C][qb][kb][r] * p.c;
                         const bool show = (key < p.Sk) && (key <= vis);
                         y = show ? y : -INFINITY;
-                        sacc[qb][kb][r] = y;
+                        sacc[C][qb][kb][r] = y;
                         mx = fmaxf(mx, y);
                     }
                 mx = max_across_halves(mx);
@@ -249,10 +250,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
                         f32x8 x;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            x[e] = fast_exp2(sacc[qb][kb][8 * t2 + e] - m_use);
+                            x[e] = fast_exp2(sacc[C][qb][kb][8 * t2 + e] - m_use);
                             rs += x[e];
                         }
-                        pn[qb][kb][t2] = E::cvt8(x);
+                        pf[C][qb][kb][t2] = E::cvt8(x);
                     }
                 lnew[qb] = l_run[qb] * alpha + rs;
                 m_run[qb] = m_new;
@@ -265,18 +266,17 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
             }
         }
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            l_run[qb] = lnew[qb];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                sacc[qb][kb] = snext[qb][kb];
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) pf[qb][kb][t2] = pn[qb][kb][t2];
-            }
-        }
+        for (int qb = 0; qb < QB; ++qb) l_run[qb] = lnew[qb];
         __syncthreads();
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+        tile_body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ntiles) tile_body(t + 1, std::integral_constant<int, 1>{});
     }
-    if (ntiles > 0) pv_tile(ldsV + ((ntiles - 1) & 1) * TILEB);  // drain: O^T += V(last)^T P(last)^T
+    if (ntiles > 0) {  // drain: O^T += V(last)^T P(last)^T  (P(last) sits in set (ntiles-1)&1)
+        if ((ntiles - 1) & 1) pv_tile(ldsV + TILEB, pf[1]);
+        else pv_tile(ldsV, pf[0]);
+    }
 
     // ---- epilogue: O = acc / l, LSE = ln2 * (m + log2 l)
     char* obase = p.o + (b * p.os[0] + h * p.os[1]) * 2;
