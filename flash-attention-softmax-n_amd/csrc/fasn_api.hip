@@ -9,17 +9,22 @@
 
 using namespace fasn;
 
+namespace fasn {
+int launch_fwd_f32(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
+int launch_bwd_f32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
+}  // namespace fasn
+
 namespace {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // rows must stay 16-byte aligned: base pointer and every non-feature stride (in 2-byte elements) % 8
-int check_view(const fasn_view4& v, bool required) {
+int check_view(const fasn_view4& v, bool required, int esize = 2) {
     if (v.ptr == nullptr) return required ? FASN_EINVAL : FASN_OK;
     if (v.stride[3] != 1) return FASN_ESTRIDE;
     if (!aligned16(v.ptr)) return FASN_EALIGN;
     for (int i = 0; i < 3; ++i)
-        if (v.stride[i] % 8 != 0) return FASN_EALIGN;
+        if (v.stride[i] % (16 / esize) != 0) return FASN_EALIGN;
     return FASN_OK;
 }
 
@@ -35,15 +40,18 @@ int internal_variant() {
 int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     if (a == nullptr) return FASN_EINVAL;
     if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0 || a->D <= 0 || a->Dv <= 0) return FASN_EINVAL;
-    if (a->dtype != FASN_DTYPE_F16 && a->dtype != FASN_DTYPE_BF16) return FASN_EDTYPE;
+    if (a->dtype != FASN_DTYPE_F16 && a->dtype != FASN_DTYPE_BF16 && a->dtype != FASN_DTYPE_F32) return FASN_EDTYPE;
     if (!fasn_supported(a->dtype, a->D, a->Dv)) return FASN_EHEADDIM;
+    const int esize = a->dtype == FASN_DTYPE_F32 ? 4 : 2;
+    // the fp32 kernels cover plain and causal attention; masks, bias and dropout are features of the 16-bit paths
+    if (esize == 4 && (a->mask.ptr || a->bias.ptr || a->dropout_p != 0.f)) return FASN_EUNSUPPORTED;
     if (!(a->dropout_p >= 0.f) || a->dropout_p >= 1.f) return FASN_EINVAL;
     if (!(a->softmax_n >= 0.f) || !(a->scale >= 0.f) || !isfinite(a->scale)) return FASN_EINVAL;
     int rc;
-    if ((rc = check_view(a->q, true))) return rc;
-    if ((rc = check_view(a->k, true))) return rc;
-    if ((rc = check_view(a->v, true))) return rc;
-    if ((rc = check_view(a->o, true))) return rc;
+    if ((rc = check_view(a->q, true, esize))) return rc;
+    if ((rc = check_view(a->k, true, esize))) return rc;
+    if ((rc = check_view(a->v, true, esize))) return rc;
+    if ((rc = check_view(a->o, true, esize))) return rc;
     if (a->bias.ptr != nullptr && a->bias_dtype != FASN_BIAS_SAME && a->bias_dtype != FASN_BIAS_F32) return FASN_EINVAL;
 
     p.q = (const char*)a->q.ptr;
@@ -108,7 +116,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     p.seed_hi = (unsigned)(a->seed >> 32) + (unsigned)(a->offset >> 32);
     p.c = a->scale * kLog2e;
     {
-        const int64_t kb = (int64_t)a->Sk * a->k.stride[2] * 2, vb = (int64_t)a->Sk * a->v.stride[2] * 2;
+        const int64_t kb = (int64_t)a->Sk * a->k.stride[2] * esize, vb = (int64_t)a->Sk * a->v.stride[2] * esize;
         if (kb <= 0 || vb <= 0 || kb >= (1ll << 31) || vb >= (1ll << 31)) return FASN_EINVAL;  // one (b,h) K/V matrix must span < 2 GiB
         p.kbytes = (unsigned)kb;
         p.vbytes = (unsigned)vb;
@@ -128,6 +136,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
 }
 
 int dispatch_fwd(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (l.dtype == FASN_DTYPE_F32) return launch_fwd_f32(p, l, s);
     switch (l.D) {
         case 32: return launch_fwd_d32(p, l, s);
         case 64: return launch_fwd_d64(p, l, s);
@@ -146,7 +155,7 @@ const char* fasn_strerror(int code) {
     switch (code) {
         case FASN_OK: return "ok";
         case FASN_EINVAL: return "invalid argument (null pointer, non-positive size, negative n/scale, bad enum)";
-        case FASN_EDTYPE: return "unsupported element type (supported: fp16, bf16)";
+        case FASN_EDTYPE: return "unsupported element type (supported: fp16, bf16, fp32)";
         case FASN_EHEADDIM: return "unsupported head dimension (supported: D == Dv in {32, 64, 128})";
         case FASN_EALIGN: return "pointer or stride breaks the 16-byte row alignment rule";
         case FASN_ESTRIDE: return "feature (last-dim) stride must be 1";
@@ -158,7 +167,7 @@ const char* fasn_strerror(int code) {
 }
 
 int fasn_supported(int32_t dtype, int32_t D, int32_t Dv) {
-    if (dtype != FASN_DTYPE_F16 && dtype != FASN_DTYPE_BF16) return 0;
+    if (dtype != FASN_DTYPE_F16 && dtype != FASN_DTYPE_BF16 && dtype != FASN_DTYPE_F32) return 0;
     if (D != Dv) return 0;
     return (D == 32 || D == 64 || D == 128) ? 1 : 0;
 }
@@ -193,10 +202,11 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
     int rc = build_fwd(&a->fwd, fp, l);
     if (rc) return rc;
     if (a->fwd.lse == nullptr || a->delta == nullptr) return FASN_EINVAL;
-    if ((rc = check_view(a->dout, true))) return rc;
-    if ((rc = check_view(a->dq, true))) return rc;
-    if ((rc = check_view(a->dk, true))) return rc;
-    if ((rc = check_view(a->dv, true))) return rc;
+    const int esize = a->fwd.dtype == FASN_DTYPE_F32 ? 4 : 2;
+    if ((rc = check_view(a->dout, true, esize))) return rc;
+    if ((rc = check_view(a->dq, true, esize))) return rc;
+    if ((rc = check_view(a->dk, true, esize))) return rc;
+    if ((rc = check_view(a->dv, true, esize))) return rc;
     BwdParams p;
     p.f = fp;
     p.dout = (const char*)a->dout.ptr;
@@ -206,7 +216,7 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
     p.delta = a->delta;
     p.scale = a->fwd.scale;
     {
-        const int64_t qb = (int64_t)a->fwd.Sq * a->fwd.q.stride[2] * 2, db = (int64_t)a->fwd.Sq * a->dout.stride[2] * 2;
+        const int64_t qb = (int64_t)a->fwd.Sq * a->fwd.q.stride[2] * esize, db = (int64_t)a->fwd.Sq * a->dout.stride[2] * esize;
         if (qb <= 0 || db <= 0 || qb >= (1ll << 31) || db >= (1ll << 31)) return FASN_EINVAL;
         p.qbytes = (unsigned)qb;
         p.dobytes = (unsigned)db;
@@ -217,6 +227,7 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
         p.dks[i] = a->dk.stride[i];
         p.dvs[i] = a->dv.stride[i];
     }
+    if (l.dtype == FASN_DTYPE_F32) return launch_bwd_f32(p, l, (hipStream_t)stream);
     return launch_bwd(p, l, (hipStream_t)stream);
 }
 

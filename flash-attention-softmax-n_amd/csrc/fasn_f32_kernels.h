@@ -1,0 +1,491 @@
+// fasn_f32_kernels.h — fp32-in / fp32-out attention-softmax_n (forward, delta, dQ, dK/dV) on the exact-fp32 matrix
+// instruction v_mfma_f32_32x32x2_f32 (64 cycles per instruction: the fp32 vector rate, 1/16 of the bf16 MFMA rate; there is
+// no TF32-class fast path on gfx950). Same orientation and tile schedule as the 16-bit kernels (fasn_fwd_kernel.h,
+// fasn_bwd_kernel.h): a lane owns a query row (forward, dQ) or a key column (dK/dV); what differs is the operand plumbing:
+//   * operand with the contraction along the feature dim: lane reads 16 B = 4 consecutive floats of its row (ds_read_b128 /
+//     global load); MFMA e of that chunk pairs lane-half 0's float e (feature 8c+e) with lane-half 1's (feature 8c+4+e)
+//   * operand with the contraction along tile rows (V^T, K^T, dO^T, Q^T): one ds_read_b32 per MFMA, row = the row that
+//     accumulator register r of this lane-half stands for, column = lane&31 — no transpose instruction needed
+//   * P / dS stay fp32: accumulator register r IS the B operand of MFMA r (no packing, no rounding)
+// Modes: plain and causal (ragged sizes handled); masks, bias and dropout are 16-bit-path features.
+// Reference: flash_attention_softmax_n/core/flash_attn.py:42-124 and tests/gpu/core/test_flash_attn.py:14 (fp32 atol 1e-3).
+#pragma once
+#include "fasn_bwd_kernel.h"
+
+namespace fasn {
+
+FASN_DEV f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// 16-byte-chunk swizzle of a [rows][D] fp32 tile: conflict-free for "row = lane&31, same chunk" ds_read_b128
+template <int D>
+FASN_DEV int swz32(int row) {
+    if constexpr (D == 32) return (row >> 1) & 7;  // 128-B rows, two per bank row
+    else return row & 15;                          // 256-B / 512-B rows
+}
+template <int D>
+FASN_DEV int off32(int row, int chunk) { return row * (D * 4) + ((chunk ^ swz32<D>(row)) << 4); }
+// scalar element (row, col)
+template <int D>
+FASN_DEV float lds_elem32(const char* tile, int row, int col) {
+    return *LDS_PTR(const float, tile + off32<D>(row, col >> 2) + (col & 3) * 4);
+}
+template <int D>
+FASN_DEV f32x4 lds_row4(const char* tile, int row, int chunk) { return *LDS_PTR(const f32x4, tile + off32<D>(row, chunk)); }
+
+// stage a [64][D] fp32 tile: buffer loads (rows past the end read as 0) -> registers -> LDS
+template <int D>
+struct Stage32 {
+    static constexpr int CPR = D / 4;                 // 16-byte chunks per row
+    static constexpr int NLD = (64 * CPR) / 256;
+    unsigned voff[NLD];
+    int loff[NLD];
+    FASN_DEV void init(int tid, int64_t row_stride) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ci = tid + i * 256;
+            const int row = ci / CPR, ch = ci % CPR;
+            voff[i] = (unsigned)(row * (int)row_stride * 4 + ch * 16);
+            loff[i] = off32<D>(row, ch);
+        }
+    }
+    FASN_DEV void gload(u32x4 (&st)[NLD], __amdgpu_buffer_rsrc_t rs, int row0, int64_t row_stride) const {
+        const int soff = row0 * (int)row_stride * 4;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) st[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], soff, 0);
+    }
+    FASN_DEV void lstore(const u32x4 (&st)[NLD], char* tile) const {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *LDS_PTR(u32x4, tile + loff[i]) = st[i];
+    }
+};
+
+// row of the accumulator register r for lane-half hi
+FASN_DEV int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int D, int MODE>
+__global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
+    constexpr int BM = 128, TILEB = 64 * D * 4, KC = D / 8, DB = D / 32;
+    using St = Stage32<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsK = smem;
+    char* const ldsV = smem + 2 * TILEB;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bh, qi;
+    block_to_work(blockIdx.x, p.B * p.H, p.nqblk, bh, qi);
+    constexpr bool causal = MODE == MODE_CAUSAL;
+    const int qblk = causal ? (p.nqblk - 1 - qi) : qi;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qblk * BM, qw0 = q0 + wave * 32, row = qw0 + l31, coff = p.Sk - p.Sq;
+    const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 4;
+    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 4;
+    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 4;
+    int ntiles = (p.Sk + 63) / 64;
+    if (causal) {
+        const int kmax = min(q0 + BM, p.Sq) - 1 + coff;
+        ntiles = min(ntiles, kmax < 0 ? 0 : (kmax / 64 + 1));
+    }
+    f32x4 qf[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        qf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < p.Sq) qf[c] = *reinterpret_cast<const f32x4*>(qbase + (int64_t)row * p.qs[2] * 4 + (2 * c + hi) * 16);
+    }
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase), 0, p.kbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase), 0, p.vbytes, 0x00020000);
+    St sK, sV;
+    sK.init(tid, p.ks[2]);
+    sV.init(tid, p.vs[2]);
+    u32x4 stK[St::NLD], stV[St::NLD];
+    const bool sink = p.n > 0.f;
+    float m_run = sink ? 0.f : -INFINITY, l_run = (sink && hi == 0) ? p.n : 0.f;
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    if (ntiles > 0) {
+        sK.gload(stK, krs, 0, p.ks[2]);
+        sV.gload(stV, vrs, 0, p.vs[2]);
+        sK.lstore(stK, ldsK);
+        sV.lstore(stV, ldsV);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < KC; ++c) retire_loads(qf[c]);
+    const int vis = causal ? (row + coff) : 0x7fffffff;
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, k0 = t * 64;
+        sK.gload(stK, krs, k0 + 64, p.ks[2]);
+        sV.gload(stV, vrs, k0 + 64, p.vs[2]);
+        const char* tK = ldsK + buf * TILEB;
+        const char* tV = ldsV + buf * TILEB;
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const f32x4 kf = lds_row4<D>(tK, kb * 32 + l31, 2 * c + hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc[kb] = mfma32(kf[e], qf[c][e], sacc[kb]);
+            }
+        }
+        // online softmax_n (log2 domain), exact every tile: the matrix pipe is the bottleneck here, not the VALU
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kb * 32 + acc_row(r, hi);
+                const float y = (key < p.Sk && key <= vis) ? sacc[kb][r] * p.c : -INFINITY;
+                sacc[kb][r] = y;
+                mx = fmaxf(mx, y);
+            }
+        mx = max_across_halves(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2(m_run - m_use);
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[kb][r] = fast_exp2(sacc[kb][r] - m_use);
+                rs += sacc[kb][r];
+            }
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
+        // O^T[d][q] += V^T[d][key] P^T[key][q]: MFMA r contracts the two keys acc_row(r,0), acc_row(r,1)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const float vf = lds_elem32<D>(tV, kb * 32 + acc_row(r, hi), d * 32 + l31);
+                    oacc[d] = mfma32(vf, sacc[kb][r], oacc[d]);
+                }
+        sK.lstore(stK, ldsK + (buf ^ 1) * TILEB);
+        sV.lstore(stV, ldsV + (buf ^ 1) * TILEB);
+        __syncthreads();
+    }
+    const float l_tot = sum_across_halves(l_run);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (row < p.Sq) {
+        if (p.lse != nullptr && hi == 0) {
+            const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+            p.lse[(int64_t)bh * p.Sq + row] = l_tot > 0.f ? (m_use + __builtin_log2f(l_tot)) * kLn2 : -INFINITY;
+        }
+        char* rp = p.o + (b * p.os[0] + h * p.os[1] + (int64_t)row * p.os[2]) * 4;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = oacc[d][4 * g + e] * inv;
+                *reinterpret_cast<f32x4*>(rp + (d * 32 + 8 * g + 4 * hi) * 4) = x;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ delta = rowsum(O o dO)
+template <int D>
+__global__ void __launch_bounds__(256) fasn_f32_delta_kernel(const BwdParams p) {
+    constexpr int LPR = D / 4, RPB = 256 / LPR;
+    const int tid = threadIdx.x, sub = tid % LPR;
+    const int64_t rows = (int64_t)p.f.B * p.f.H * p.f.Sq;
+    const int64_t gr = (int64_t)blockIdx.x * RPB + tid / LPR;
+    float acc = 0.f;
+    if (gr < rows) {
+        const int i = (int)(gr % p.f.Sq), bh = (int)(gr / p.f.Sq), b = bh / p.f.H, h = bh % p.f.H;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.f.o + (b * p.f.os[0] + h * p.f.os[1] + (int64_t)i * p.f.os[2]) * 4 + sub * 16);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(p.dout + (b * p.dos[0] + h * p.dos[1] + (int64_t)i * p.dos[2]) * 4 + sub * 16);
+        acc = a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) acc += __shfl_xor(acc, o);
+    if (gr < rows && sub == 0) p.delta[gr] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <int D, int MODE>
+__global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
+    const FwdParams& p = bp.f;
+    constexpr int BM = 128, TILEB = 64 * D * 4, KC = D / 8, DB = D / 32;
+    using St = Stage32<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsK = smem;
+    char* const ldsV = smem + 2 * TILEB;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bh, qi;
+    block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
+    constexpr bool causal = MODE == MODE_CAUSAL;
+    const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qblk * BM, qw0 = q0 + wave * 32, row = qw0 + l31, coff = p.Sk - p.Sq;
+    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 4;
+    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 4;
+    int ntiles = (p.Sk + 63) / 64;
+    if (causal) {
+        const int kmax = min(q0 + BM, p.Sq) - 1 + coff;
+        ntiles = min(ntiles, kmax < 0 ? 0 : (kmax / 64 + 1));
+    }
+    f32x4 qf[KC], dof[KC];
+    const bool ok = row < p.Sq;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        qf[c] = dof[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            qf[c] = *reinterpret_cast<const f32x4*>(p.q + (b * p.qs[0] + h * p.qs[1] + (int64_t)row * p.qs[2]) * 4 + (2 * c + hi) * 16);
+            dof[c] = *reinterpret_cast<const f32x4*>(bp.dout + (b * bp.dos[0] + h * bp.dos[1] + (int64_t)row * bp.dos[2]) * 4 + (2 * c + hi) * 16);
+        }
+    }
+    float lse2 = ok ? p.lse[(int64_t)bh * p.Sq + row] : 0.f;
+    lse2 = (lse2 == -INFINITY) ? INFINITY : lse2 * kLog2e;
+    float dlt = ok ? bp.delta[(int64_t)bh * p.Sq + row] : 0.f;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase), 0, p.kbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase), 0, p.vbytes, 0x00020000);
+    St sK, sV;
+    sK.init(tid, p.ks[2]);
+    sV.init(tid, p.vs[2]);
+    u32x4 stK[St::NLD], stV[St::NLD];
+    f32x16 dqacc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[d][r] = 0.f;
+    if (ntiles > 0) {
+        sK.gload(stK, krs, 0, p.ks[2]);
+        sV.gload(stV, vrs, 0, p.vs[2]);
+        sK.lstore(stK, ldsK);
+        sV.lstore(stV, ldsV);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        retire_loads(qf[c]);
+        retire_loads(dof[c]);
+    }
+    retire_loads(lse2);
+    retire_loads(dlt);
+    const int vis = causal ? (row + coff) : 0x7fffffff;
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, k0 = t * 64;
+        sK.gload(stK, krs, k0 + 64, p.ks[2]);
+        sV.gload(stV, vrs, k0 + 64, p.vs[2]);
+        const char* tK = ldsK + buf * TILEB;
+        const char* tV = ldsV + buf * TILEB;
+        f32x16 sacc[2], pacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = pacc[kb][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const f32x4 kf = lds_row4<D>(tK, kb * 32 + l31, 2 * c + hi);
+                const f32x4 vf = lds_row4<D>(tV, kb * 32 + l31, 2 * c + hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sacc[kb] = mfma32(kf[e], qf[c][e], sacc[kb]);
+                    pacc[kb] = mfma32(vf[e], dof[c][e], pacc[kb]);
+                }
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kb * 32 + acc_row(r, hi);
+                float pv = fast_exp2(__builtin_fmaf(sacc[kb][r], p.c, -lse2));
+                pv = (key < p.Sk && key <= vis) ? pv : 0.f;
+                sacc[kb][r] = pv * (pacc[kb][r] - dlt);   // dS^T (without the scale factor)
+            }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const float kt = lds_elem32<D>(tK, kb * 32 + acc_row(r, hi), d * 32 + l31);
+                    dqacc[d] = mfma32(kt, sacc[kb][r], dqacc[d]);
+                }
+        sK.lstore(stK, ldsK + (buf ^ 1) * TILEB);
+        sV.lstore(stV, ldsV + (buf ^ 1) * TILEB);
+        __syncthreads();
+    }
+    if (ok) {
+        char* rp = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1] + (int64_t)row * bp.dqs[2]) * 4;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = dqacc[d][4 * g + e] * bp.scale;
+                *reinterpret_cast<f32x4*>(rp + (d * 32 + 8 * g + 4 * hi) * 4) = x;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <int D, int MODE>
+__global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) {
+    const FwdParams& p = bp.f;
+    constexpr int BN = 128, TILEB = 64 * D * 4, KC = D / 8, DB = D / 32;
+    using St = Stage32<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsQ = smem;
+    char* const ldsDO = smem + 2 * TILEB;
+    float* const ldsLse = reinterpret_cast<float*>(smem + 4 * TILEB);
+    float* const ldsDlt = ldsLse + 2 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bh, kblk;
+    block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
+    constexpr bool causal = MODE == MODE_CAUSAL;
+    const int b = bh / p.H, h = bh % p.H;
+    const int kw0 = kblk * BN + wave * 32, key = kw0 + l31, coff = p.Sk - p.Sq;
+    const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 4;
+    const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 4;
+    const float* lsebase = p.lse + (int64_t)bh * p.Sq;
+    const float* dltbase = bp.delta + (int64_t)bh * p.Sq;
+    const int ntq = (p.Sq + 63) / 64;
+    int tq0 = 0;
+    if (causal) {
+        const int first_row = kblk * BN - coff;
+        tq0 = first_row <= 0 ? 0 : first_row / 64;
+    }
+    f32x4 kf[KC], vf[KC];
+    const bool ok = key < p.Sk;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        kf[c] = vf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            kf[c] = *reinterpret_cast<const f32x4*>(p.k + (b * p.ks[0] + h * p.ks[1] + (int64_t)key * p.ks[2]) * 4 + (2 * c + hi) * 16);
+            vf[c] = *reinterpret_cast<const f32x4*>(p.v + (b * p.vs[0] + h * p.vs[1] + (int64_t)key * p.vs[2]) * 4 + (2 * c + hi) * 16);
+        }
+    }
+    f32x16 dkacc[DB], dvacc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dkacc[d][r] = dvacc[d][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qbase), 0, bp.qbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dobase), 0, bp.dobytes, 0x00020000);
+    St sQ, sD;
+    sQ.init(tid, p.qs[2]);
+    sD.init(tid, bp.dos[2]);
+    u32x4 stQ[St::NLD], stD[St::NLD];
+    float stL = 0.f, stX = 0.f;
+    auto stats_gload = [&](int row0) {
+        if (tid < 64) {
+            const int gr = row0 + tid;
+            float l = 0.f, x = 0.f;
+            if (gr < p.Sq) {
+                l = lsebase[gr];
+                x = dltbase[gr];
+            }
+            stL = (l == -INFINITY) ? INFINITY : l * kLog2e;
+            stX = x;
+        }
+    };
+    auto stats_lstore = [&](int buf) {
+        if (tid < 64) {
+            ldsLse[buf * 64 + tid] = stL;
+            ldsDlt[buf * 64 + tid] = stX;
+        }
+    };
+    if (tq0 < ntq) {
+        sQ.gload(stQ, qrs, tq0 * 64, p.qs[2]);
+        sD.gload(stD, drs, tq0 * 64, bp.dos[2]);
+        stats_gload(tq0 * 64);
+        sQ.lstore(stQ, ldsQ);
+        sD.lstore(stD, ldsDO);
+        stats_lstore(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        retire_loads(kf[c]);
+        retire_loads(vf[c]);
+    }
+    for (int tq = tq0; tq < ntq; ++tq) {
+        const int buf = (tq - tq0) & 1, r0 = tq * 64;
+        sQ.gload(stQ, qrs, r0 + 64, p.qs[2]);
+        sD.gload(stD, drs, r0 + 64, bp.dos[2]);
+        stats_gload(r0 + 64);
+        const char* tQ = ldsQ + buf * TILEB;
+        const char* tD = ldsDO + buf * TILEB;
+        const float* tL = ldsLse + buf * 64;
+        const float* tX = ldsDlt + buf * 64;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = pacc[r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const f32x4 qa = lds_row4<D>(tQ, qb * 32 + l31, 2 * c + hi);
+                const f32x4 da = lds_row4<D>(tD, qb * 32 + l31, 2 * c + hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sacc = mfma32(qa[e], kf[c][e], sacc);   // S[q][key]
+                    pacc = mfma32(da[e], vf[c][e], pacc);   // dP[q][key]
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = qb * 32 + acc_row(r, hi);
+                const int row = r0 + rr;
+                float pv = fast_exp2(__builtin_fmaf(sacc[r], p.c, -tL[rr]));
+                pv = (ok && row < p.Sq && (!causal || key <= row + coff)) ? pv : 0.f;
+                sacc[r] = pv;
+                pacc[r] = pv * (pacc[r] - tX[rr]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const int rr = qb * 32 + acc_row(r, hi);
+                    const float dot = lds_elem32<D>(tD, rr, d * 32 + l31);
+                    const float qt = lds_elem32<D>(tQ, rr, d * 32 + l31);
+                    dvacc[d] = mfma32(dot, sacc[r], dvacc[d]);
+                    dkacc[d] = mfma32(qt, pacc[r], dkacc[d]);
+                }
+        }
+        sQ.lstore(stQ, ldsQ + (buf ^ 1) * TILEB);
+        sD.lstore(stD, ldsDO + (buf ^ 1) * TILEB);
+        stats_lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (ok) {
+        char* rk = bp.dk + (b * bp.dks[0] + h * bp.dks[1] + (int64_t)key * bp.dks[2]) * 4;
+        char* rv = bp.dv + (b * bp.dvs[0] + h * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 4;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 x, y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = dkacc[d][4 * g + e] * bp.scale;
+                    y[e] = dvacc[d][4 * g + e];
+                }
+                *reinterpret_cast<f32x4*>(rk + (d * 32 + 8 * g + 4 * hi) * 4) = x;
+                *reinterpret_cast<f32x4*>(rv + (d * 32 + 8 * g + 4 * hi) * 4) = y;
+            }
+    }
+}
+
+}  // namespace fasn

@@ -20,7 +20,7 @@ from . import _lib
 from ._lib import BwdArgs, FwdArgs, View4
 
 _SUPPORTED_D = (32, 64, 128)
-_DTYPES = {torch.float16: _lib.FASN_DTYPE_F16, torch.bfloat16: _lib.FASN_DTYPE_BF16}
+_DTYPES = {torch.float16: _lib.FASN_DTYPE_F16, torch.bfloat16: _lib.FASN_DTYPE_BF16, torch.float32: _lib.FASN_DTYPE_F32}
 
 
 def _view4(t: Optional[Tensor]) -> View4:
@@ -36,12 +36,13 @@ def _view4(t: Optional[Tensor]) -> View4:
 
 
 def _rows_ok(t: Tensor) -> bool:
-    """16-byte row alignment rule of the C ABI for 2-byte element tensors."""
+    """16-byte row alignment rule of the C ABI (strides % 8 elements for 16-bit types, % 4 for fp32)."""
     if t.stride(-1) != 1 and t.size(-1) != 1:
         return False
     if t.data_ptr() % 16 != 0:
         return False
-    return all(t.stride(i) % 8 == 0 or t.size(i) == 1 for i in range(t.dim() - 1))
+    q = 16 // t.element_size()
+    return all(t.stride(i) % q == 0 or t.size(i) == 1 for i in range(t.dim() - 1))
 
 
 def _canon(t: Tensor) -> Tensor:
@@ -122,7 +123,10 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
         raise RuntimeError("flash_attention_softmax_n_amd runs on MI355X device tensors only; got a CPU tensor "
                            "(there is deliberately no CPU fallback)")
     if query.dtype not in _DTYPES:
-        raise NotImplementedError(f"dtype {query.dtype}: the gfx950 MFMA path supports torch.float16 and torch.bfloat16")
+        raise NotImplementedError(f"dtype {query.dtype}: supported are torch.float16, torch.bfloat16 and torch.float32")
+    if query.dtype == torch.float32 and (mask is not None or bias is not None or (dropout_p and dropout_p > 0)):
+        raise NotImplementedError("fp32 inputs run on the exact-fp32 MFMA kernels, which cover plain and causal attention; "
+                                  "attn_mask, attn_bias and dropout need fp16/bf16 inputs")
     if key.dtype != query.dtype or value.dtype != query.dtype:
         raise TypeError("query, key and value must share one dtype")
     dropout_p = float(dropout_p or 0.0)
@@ -195,7 +199,8 @@ def flash_attention_n(
 ) -> Tensor:
     """Fused attention with softmax_n on MI355X; drop-in for flash_attention_softmax_n.flash_attention_n.
 
-    :param query: [B, H, L, E] fp16/bf16 device tensor.
+    :param query: [B, H, L, E] fp16 / bf16 device tensor (fp32 also accepted: exact-fp32 kernels, ~1/16 of the bf16 rate,
+                  no mask / bias / dropout).
     :param key: [B, H, S, E] (or [B, S, E], shared by all heads).
     :param value: [B, H, S, Ev].
     :param softmax_n_param: n >= 0; real values allowed (the reference's SDPA path takes integers only).

@@ -19,7 +19,8 @@
  *   - returns FASN_OK (0) or a negative FASN_E* code; never throws, never aborts.
  *
  * Tensor layout: 4-D (batch, head, seq, feature) addressed by element strides; the feature stride
- * must be 1 and base pointers / other strides must keep every row 16-byte aligned. A stride of 0 is
+ * must be 1 and base pointers / other strides must keep every row 16-byte aligned (strides % 8 elements for the 16-bit
+ * types, % 4 for fp32). A stride of 0 is
  * a broadcast dimension (mask, bias, and the head dimension of K/V for shared-KV layouts).
  */
 #ifndef FASN_H_
@@ -45,7 +46,8 @@ extern "C" {
 #define FASN_EUNSUPPORTED (-7)/* valid request this build does not implement (e.g. dropout) */
 #define FASN_EWORKSPACE (-8)  /* workspace missing or too small */
 
-/* element types of q/k/v/o/do/dq/dk/dv */
+/* element types of q/k/v/o/do/dq/dk/dv (FASN_DTYPE_F32 = 2, defined below: exact-fp32 MFMA kernels, plain and causal
+   attention only - mask, bias and dropout need a 16-bit type) */
 #define FASN_DTYPE_F16 0
 #define FASN_DTYPE_BF16 1
 

@@ -40,7 +40,7 @@ def test_supported_matrix(pkg):
         assert lib.fasn_supported(0, d, d) == 1 and lib.fasn_supported(1, d, d) == 1
     assert lib.fasn_supported(1, 64, 32) == 0
     assert lib.fasn_supported(1, 96, 96) == 0
-    assert lib.fasn_supported(2, 64, 64) == 0
+    assert lib.fasn_supported(2, 64, 64) == 1 and lib.fasn_supported(3, 64, 64) == 0
 
 
 def _args(pkg, **over):
@@ -62,7 +62,8 @@ def test_argument_validation_codes(pkg):
     lib = pkg._lib.load()
     assert lib.fasn_fwd(None, None) == -1
     assert lib.fasn_fwd(_args(pkg, B=0), None) == -1
-    assert lib.fasn_fwd(_args(pkg, dtype=2), None) == -2
+    assert lib.fasn_fwd(_args(pkg, dtype=3), None) == -2
+    assert lib.fasn_fwd(_args(pkg, dtype=2, dropout_p=0.5), None) == -7   # fp32: no dropout
     assert lib.fasn_fwd(_args(pkg, D=96, Dv=96), None) == -3
     assert lib.fasn_fwd(_args(pkg, dropout_p=1.0), None) == -1
     assert lib.fasn_fwd(_args(pkg, dropout_p=-0.1), None) == -1

@@ -264,7 +264,50 @@ def test_real_valued_n_and_signature_aliases(pkg, dev):
     with pytest.raises(ValueError):
         pkg.flash_attention_n(q, k, v, dropout_p=1.0)
     with pytest.raises(NotImplementedError):
-        pkg.flash_attention_n(q.float(), k.float(), v.float())
+        pkg.flash_attention_n(q.double(), k.double(), v.double())
+    with pytest.raises(NotImplementedError):
+        pkg.flash_attention_n(q.float(), k.float(), v.float(), dropout_p=0.1)
+
+
+# ---------------------------------------------------------------- fp32 (exact-fp32 MFMA kernels)
+@pytest.mark.parametrize("is_causal", [False, True])
+@pytest.mark.parametrize("scale", [None, 0.1, 0.5])
+@pytest.mark.parametrize("n", [0, 1, 4])
+def test_flash_attention_n_fp32_reference_grid(pkg, dev, n, scale, is_causal):
+    """reference tests/gpu/core/test_flash_attn.py:10-48 for float32: shape (6,1,1024,64), atol 1e-3, fwd + grads"""
+    shape = (6, 1, 1024, 64)
+    q, k, v = (_rand(shape, torch.float32, dev, s).requires_grad_() for s in (1, 2, 3))
+    do = _rand(shape, torch.float32, dev, 4, std=1.0)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, scale=scale, is_causal=is_causal)
+    assert out.dtype == torch.float32
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=float(n), scale=scale, is_causal=is_causal)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        err = (got.detach().cpu() - want).abs().max().item()
+        assert err <= 1e-3, f"{nm}: {err:.3e} > reference atol 1e-3"
+        assert err <= 2e-5 * max(want.abs().max().item(), 1.0), f"{nm}: {err:.3e} (fp32 MFMA should be near exact)"
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 100, 32), (1, 3, 257, 128), (2, 1, 3, 8), (1, 2, 130, 96)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fp32_ragged_sizes_and_golden(pkg, dev, golden_dir, shape, causal):
+    B, H, L, E = shape
+    S = L + 7
+    q, k, v = (_rand(sh, torch.float32, dev, s).requires_grad_() for sh, s in (((B, H, L, E), 1), ((B, H, S, E), 2), ((B, H, S, E), 3)))
+    do = _rand((B, H, L, E), torch.float32, dev, 4, std=1.0)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, is_causal=causal)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=0.5, is_causal=causal)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        assert (got.detach().cpu() - want).abs().max().item() <= 2e-5 * max(want.abs().max().item(), 1.0), nm
+    # BASELINE config 1 in fp32 against the reference's own output (golden g1), n = 1
+    g = np.load(os.path.join(golden_dir, "g1_c1.npz"))
+    tag = f"n1.0_c{int(causal)}"
+    gq, gk, gv = (torch.from_numpy(g[x]).to(dev).requires_grad_() for x in ("q", "k", "v"))
+    go = pkg.flash_attention_n(gq, gk, gv, softmax_n_param=1, is_causal=causal)
+    go.backward(torch.from_numpy(g["dout"]).to(dev))
+    for got, name in ((go, "o"), (gq.grad, "dq"), (gk.grad, "dk"), (gv.grad, "dv")):
+        assert np.abs(got.detach().cpu().numpy() - g[f"{name}_{tag}"]).max() <= 5e-6
 
 
 # ---------------------------------------------------------------- dropout
