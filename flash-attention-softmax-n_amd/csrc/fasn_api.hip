@@ -116,7 +116,8 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     p.seed_hi = (unsigned)(a->seed >> 32) + (unsigned)(a->offset >> 32);
     p.c = a->scale * kLog2e;
     {
-        const int64_t kb = (int64_t)a->Sk * a->k.stride[2] * esize, vb = (int64_t)a->Sk * a->v.stride[2] * esize;
+        // extent of one (b,h) matrix = last row start + one row (a length-1 sequence may carry stride 0)
+        const int64_t kb = ((int64_t)(a->Sk - 1) * a->k.stride[2] + a->D) * esize, vb = ((int64_t)(a->Sk - 1) * a->v.stride[2] + a->Dv) * esize;
         if (kb <= 0 || vb <= 0 || kb >= (1ll << 31) || vb >= (1ll << 31)) return FASN_EINVAL;  // one (b,h) K/V matrix must span < 2 GiB
         p.kbytes = (unsigned)kb;
         p.vbytes = (unsigned)vb;
@@ -216,7 +217,8 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
     p.delta = a->delta;
     p.scale = a->fwd.scale;
     {
-        const int64_t qb = (int64_t)a->fwd.Sq * a->fwd.q.stride[2] * esize, db = (int64_t)a->fwd.Sq * a->dout.stride[2] * esize;
+        const int64_t qb = ((int64_t)(a->fwd.Sq - 1) * a->fwd.q.stride[2] + a->fwd.D) * esize;
+        const int64_t db = ((int64_t)(a->fwd.Sq - 1) * a->dout.stride[2] + a->fwd.Dv) * esize;
         if (qb <= 0 || db <= 0 || qb >= (1ll << 31) || db >= (1ll << 31)) return FASN_EINVAL;
         p.qbytes = (unsigned)qb;
         p.dobytes = (unsigned)db;
