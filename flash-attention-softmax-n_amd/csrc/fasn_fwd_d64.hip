@@ -34,6 +34,12 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 40: return launch_fwd_ring<Tag, 64, 2, 2>(p, l.mode, s);
         case 41: return launch_fwd_ring<Tag, 64, 1, 3>(p, l.mode, s);
         case 42: return launch_fwd_ring<Tag, 64, 1, 2>(p, l.mode, s);
+        case 50: return launch_fwd_split<Tag, 64, 2, 2>(p, l.mode, s);
+        case 51: return launch_fwd_split<Tag, 64, 1, 3>(p, l.mode, s);
+        case 52: return launch_fwd_split<Tag, 64, 1, 2>(p, l.mode, s);
+        case 5: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 1>(p, l.mode, s);
+        case 7: return launch_fwd_pipe_mode<Tag, 64, 2, 1, 1>(p, l.mode, s);
+        case 8: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 1>(p, l.mode, s);
         case 4: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 1, 2>(p, l.mode, s); break;
         case 6: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 2, 1>(p, l.mode, s); break;
         case 9: if (!gen) return launch_fwd_pp_mode<Tag, 64, 2>(p, l.mode, s); break;

@@ -11,7 +11,9 @@
 
 namespace fasn {
 
-template <typename Tag, int D, int QB, int MODE, int OCC>
+// BURST: fetch every K / V fragment of the iteration first, then issue the 16*QB MFMAs back to back, then the exponentials
+// (pinned with sched_barrier): the matrix pipe drains the burst while the VALU phase runs (tools/ubench3.cpp pattern).
+template <typename Tag, int D, int QB, int MODE, int OCC, int BURST = 0>
 __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams p) {
     static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "masked / biased attention uses fasn_fwd_kernel");
     using E = ET<Tag>;
@@ -195,8 +197,44 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
 
         if (!need_mask) {
             // ---- ONE basic block: 16*QB MFMAs (PV of the previous tile, QK^T of the next) + the exponentials of this tile
-            pv_tile(tVp, pf[C ^ 1]);
-            qk_tile(tKn, sacc[C ^ 1]);
+            if (BURST) {
+                vec8 vfr[2][2][DB], kfr[2][KS];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                        for (int d = 0; d < DB; ++d) vfr[kb][t2][d] = lds_read_trfrag<E, D>(tVp, kb * 32 + 16 * t2, d, lane);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) kfr[kb][ks] = lds_read_rowfrag<E, D>(tKn, kb * 32 + l31, ks, hi);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                        for (int d = 0; d < DB; ++d)
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vfr[kb][t2][d], pf[C ^ 1][qb][kb][t2], oacc[qb][d]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[C ^ 1][qb][kb][r] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) sacc[C ^ 1][qb][kb] = E::mfma(kfr[kb][ks], qf[qb][ks], sacc[C ^ 1][qb][kb]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                pv_tile(tVp, pf[C ^ 1]);
+                qk_tile(tKn, sacc[C ^ 1]);
+            }
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 float rs = 0.f;

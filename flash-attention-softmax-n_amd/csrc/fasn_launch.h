@@ -4,6 +4,7 @@
 #include "fasn_fwd_kernel.h"
 #include "fasn_fwd_pipe.h"
 #include "fasn_fwd_pp.h"
+#include "fasn_fwd_split.h"
 
 namespace fasn {
 
@@ -38,12 +39,12 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
-template <typename Tag, int D, int QB, int MODE, int OCC>
+template <typename Tag, int D, int QB, int MODE, int OCC, int BURST = 0>
 int launch_fwd_pipe_one(FwdParams p, hipStream_t s) {
     constexpr int BM = 4 * QB * 32;
     constexpr int smem = 4 * KT * D * 2;
     p.nqblk = (p.Sq + BM - 1) / BM;
-    auto kern = fasn_fwd_pipe_kernel<Tag, D, QB, MODE, OCC>;
+    auto kern = fasn_fwd_pipe_kernel<Tag, D, QB, MODE, OCC, BURST>;
     if (smem > 48 * 1024) {
         static bool done = false;
         if (!done) {
@@ -81,6 +82,23 @@ template <typename Tag, int D, int QB, int OCC>
 int launch_fwd_ring(const FwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_PLAIN) return launch_fwd_ring_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
     return launch_fwd_ring_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
+}
+
+// key-block-split kernel (fasn_fwd_split.h)
+template <typename Tag, int D, int QB, int MODE, int OCC>
+int launch_fwd_split_one(FwdParams p, hipStream_t s) {
+    constexpr int BM = 4 * QB * 32;
+    constexpr int smem = 4 * KT * D * 2;
+    p.nqblk = (p.Sq + BM - 1) / BM;
+    auto kern = fasn_fwd_split_kernel<Tag, D, QB, MODE, OCC>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+template <typename Tag, int D, int QB, int OCC>
+int launch_fwd_split(const FwdParams& p, int mode, hipStream_t s) {
+    if (mode == MODE_PLAIN) return launch_fwd_split_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
+    return launch_fwd_split_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
 }
 
 // 8-wave workgroups of the plain kernel (QB 32-row blocks per wave), optional static priority for waves 4-7
@@ -129,10 +147,10 @@ int launch_fwd_pp_mode(const FwdParams& p, int mode, hipStream_t s) {
 }
 
 // pipelined kernel for plain / causal; the general (mask / bias) mode stays on fasn_fwd_kernel
-template <typename Tag, int D, int QB, int OCC>
+template <typename Tag, int D, int QB, int OCC, int BURST = 0>
 int launch_fwd_pipe_mode(const FwdParams& p, int mode, hipStream_t s) {
-    if (mode == MODE_PLAIN) return launch_fwd_pipe_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
-    return launch_fwd_pipe_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
+    if (mode == MODE_PLAIN) return launch_fwd_pipe_one<Tag, D, QB, MODE_PLAIN, OCC, BURST>(p, s);
+    return launch_fwd_pipe_one<Tag, D, QB, MODE_CAUSAL, OCC, BURST>(p, s);
 }
 
 // dropout instantiations: plain, causal, and the element-load general kernel (any mask / bias combination)
