@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 
     int bh, qi;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
-    const bool causal = (MODE == MODE_CAUSAL) || (MODE == MODE_GENERAL && p.causal);
+    const bool causal = (MODE == MODE_CAUSAL) || ((MODE == MODE_GENERAL || MODE == MODE_GENERAL_SLOW) && p.causal);
     const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * BM;
@@ -191,13 +191,58 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         retire_loads(dlt[qb]);
     }
 
+    // MODE_GENERAL (vector path, same scheme as the forward): per-(b,h) buffer descriptors for bias / mask, 4 keys per load,
+    // the bias folded into the S accumulator's initial value (S' = bias*log2e/c + q.k), the 0/1 mask bytes multiplied
+    // into P. An absent operand gets a zero-range descriptor (bias reads 0) / an all-ones OR word (mask keeps everything).
+    constexpr bool VEC = MODE == MODE_GENERAL;
+    __amdgpu_buffer_rsrc_t brs, mrs;
+    unsigned bvo[QB], mvo[QB];
+    u32x2 braw[QB][2][4];
+    const uint32_t nomask = (VEC && p.mask == nullptr) ? 0x01010101u : 0u;
+    const float binv = (VEC && p.bias != nullptr) ? kLog2e / p.c : 0.f;
+    auto bias_gload = [&](int t) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    braw[qb][kb][g] = __builtin_amdgcn_raw_buffer_load_b64(brs, bvo[qb] + (kb * 32 + 8 * g) * 2, t * (KT * 2), 0);
+    };
+    if (VEC) {
+        const char* bb = p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
+        const char* mb = p.mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
+        brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bb), 0, p.bias ? p.bias_bytes : 0u, 0x00020000);
+        mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mb), 0, p.mask ? p.mask_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int rowc = min(qw0 + qb * 32 + l31, p.Sq - 1);
+            bvo[qb] = (unsigned)((rowc * p.bs[2] + 4 * hi) * 2);
+            mvo[qb] = (unsigned)(rowc * p.ms[2] + 4 * hi);
+        }
+        bias_gload(0);
+    }
+
     const int wave_first_vis = qw0 + coff;
     const int wave_last_vis = qw0 + QB * 32 - 1 + coff;
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         const int k0 = t * KT;
-        if (t + 1 < ntiles) {
+        uint32_t mraw[QB][2][4];
+        if (VEC) {   // unconditional and older than the K/V prefetch in the vmcnt queue
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        mraw[qb][kb][g] = __builtin_amdgcn_raw_buffer_load_b32(mrs, mvo[qb] + kb * 32 + 8 * g, k0, 0) | nomask;
+            __builtin_amdgcn_sched_barrier(0);
+            tsK.gload(stK, krs, k0 + KT, p.ks[2]);   // past-the-end tiles read back as zeros
+            tsV.gload(stV, vrs, k0 + KT, p.vs[2]);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (t + 1 < ntiles) {
             tsK.gload(stK, krs, k0 + KT, p.ks[2]);
             tsV.gload(stV, vrs, k0 + KT, p.vs[2]);
         }
@@ -207,7 +252,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
             need_mask = (k0 + KT - 1) > wave_first_vis;
         }
         if (k0 + KT > p.Sk) need_mask = true;
-        if (MODE == MODE_GENERAL) need_mask = true;
+        if (MODE == MODE_GENERAL_SLOW) need_mask = true;
 
         if (!skip) {
             const char* tK = ldsK + buf * TILEB;
@@ -219,7 +264,12 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        sacc[qb][kb][r] = 0.f;
+                        if (VEC) {
+                            const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
+                            sacc[qb][kb][r] = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * binv;
+                        } else {
+                            sacc[qb][kb][r] = 0.f;
+                        }
                         pacc[qb][kb][r] = 0.f;
                     }
 #pragma unroll
@@ -250,7 +300,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                         if (decltype(MASKED)::value) {
                             const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                             show = (key < p.Sk) && (key <= vis);
-                            if (MODE == MODE_GENERAL) {
+                            if (MODE == MODE_GENERAL_SLOW) {
                                 const bool inb = show && (row < p.Sq);
                                 if (p.bias != nullptr && inb) {
                                     const int64_t bo = b * p.bs[0] + h * p.bs[1] + (int64_t)row * p.bs[2] + (int64_t)key * p.bs[3];
@@ -265,7 +315,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                                 }
                             }
                         }
-                        float pv = (MODE == MODE_GENERAL) ? fast_exp2(y - lse2[qb]) : fast_exp2(__builtin_fmaf(sacc[qb][kb][r], p.c, -lse2[qb]));
+                        float pv = (MODE == MODE_GENERAL_SLOW) ? fast_exp2(y - lse2[qb]) : fast_exp2(__builtin_fmaf(sacc[qb][kb][r], p.c, -lse2[qb]));
+                        if (VEC) pv *= (float)((mraw[qb][kb][r >> 2] >> (8 * (r & 3))) & 0xffu);
                         if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                         float dp = pacc[qb][kb][r];
                         if (DROP) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
@@ -300,7 +351,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                         for (int qb = 0; qb < QB; ++qb) dqacc[qb][d] = E::mfma(ktf, dsf[qb][kb][t2], dqacc[qb][d]);
                     }
         }
-        if (t + 1 < ntiles) {
+        if (VEC) bias_gload(t + 1);   // newest entry of the vmcnt queue; lands during the next tile's prologue
+        if (VEC || t + 1 < ntiles) {
             tsK.lstore(stK, ldsK + (buf ^ 1) * TILEB);
             tsV.lstore(stV, ldsV + (buf ^ 1) * TILEB);
         }
@@ -358,7 +410,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
 
     int bh, kblk;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
-    const bool causal = (MODE == MODE_CAUSAL) || (MODE == MODE_GENERAL && p.causal);
+    const bool causal = (MODE == MODE_CAUSAL) || ((MODE == MODE_GENERAL || MODE == MODE_GENERAL_SLOW) && p.causal);
     const int b = bh / p.H, h = bh % p.H;
     const int kw0 = kblk * BN + wave * (KB * 32);  // first key of this wave
     const int coff = p.Sk - p.Sq;
@@ -443,6 +495,66 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         tsD.lstore(stD, ldsDO);
         stats_lstore(0);
     }
+
+    // MODE_GENERAL (vector path): a lane owns a key column and register r a query row - the transpose of how bias / mask
+    // rows lie in memory. Per q-tile the workgroup stages ONE combined additive tile [64 rows][BN keys] of 16-bit values in
+    // LDS (bias where the mask byte is set, -inf where it is clear; coalesced 16-byte bias / 8-byte mask buffer loads,
+    // rows or keys past the end read back as "hidden") and every wave fetches its 32 columns with the same transposed
+    // read that feeds the MFMAs (ds_read_b64_tr_b16: 4 consecutive rows of one key column = accumulator registers 4g..4g+3).
+    // The tile initialises the S accumulator (S' = add*log2e/c + q.k), so the element pass is the plain one.
+    constexpr bool VEC = MODE == MODE_GENERAL;
+    constexpr int BN_ = 4 * KB * 32;
+    constexpr int ADDB = QT * BN_ * 2;              // bytes of one additive tile = BN_/128 swizzled [64][128] images
+    constexpr int ACH = (QT * BN_ / 8) / 256;       // 8-key chunks per thread
+    char* const ldsAdd = smem + 4 * TILEB + 4 * QT * 4;   // [2][ADDB]
+    __amdgpu_buffer_rsrc_t brs, mrs;
+    unsigned abvo[ACH], amvo[ACH];
+    int aloff[ACH];
+    u32x4 stA[ACH];
+    u32x2 stM[ACH];
+    const uint32_t nomask = (VEC && p.mask == nullptr) ? 0x01010101u : 0u;
+    const float binv = VEC ? kLog2e / p.c : 0.f;
+    const uint32_t ninf16 = std::is_same<Tag, bf16_tag>::value ? 0xFF80u : 0xFC00u;   // -inf in the 16-bit type
+    if (VEC) {
+        const char* bb = p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
+        const char* mb = p.mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
+        brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bb), 0, p.bias ? p.bias_bytes : 0u, 0x00020000);
+        mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mb), 0, p.mask ? p.mask_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int ci = tid + i * 256;
+            const int row = ci / (BN_ / 8), kc = ci % (BN_ / 8);
+            abvo[i] = (unsigned)((row * p.bs[2] + kc * 8) * 2);
+            amvo[i] = (unsigned)(row * p.ms[2] + kc * 8);
+            aloff[i] = (kc >> 4) * (QT * 256) + tile_off<128>(row, kc & 15);
+        }
+    }
+    auto add_gload = [&](int row0) {
+        const int kcol0 = kblk * BN_;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            stA[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, abvo[i], (row0 * (int)p.bs[2] + kcol0) * 2, 0);
+            stM[i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, amvo[i], row0 * (int)p.ms[2] + kcol0, 0);
+        }
+    };
+    auto add_lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            u32x4 o;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t mw = (stM[i][w >> 1] | nomask) >> (16 * (w & 1));   // mask bytes of keys 2w, 2w+1
+                const uint32_t lo = (mw & 0xffu) ? (stA[i][w] & 0xffffu) : ninf16;
+                const uint32_t hi16 = (mw & 0xff00u) ? (stA[i][w] >> 16) : ninf16;
+                o[w] = lo | (hi16 << 16);
+            }
+            *LDS_PTR(u32x4, ldsAdd + buf * ADDB + aloff[i]) = o;
+        }
+    };
+    if (VEC && tq0 < ntq) {
+        add_gload(tq0 * QT);
+        add_lstore(0);
+    }
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
@@ -459,9 +571,11 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             tsQ.gload(stQ, qrs, r0 + QT, p.qs[2]);
             tsD.gload(stD, drs, r0 + QT, bp.dos[2]);
             stats_gload(r0 + QT);
+            if (VEC) add_gload(r0 + QT);
         }
         const char* tQ = ldsQ + buf * TILEB;
         const char* tD = ldsDO + buf * TILEB;
+        const char* tA = ldsAdd + buf * ADDB;
         const float* tL = ldsLse + buf * QT;
         const float* tX = ldsDlt + buf * QT;
 
@@ -472,7 +586,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             need_mask = (r0 + coff) < (kw0 + KB * 32 - 1);           // the first row does not see all my keys
         }
         if (r0 + QT > p.Sq || kw0 + KB * 32 > p.Sk) need_mask = true;
-        if (MODE == MODE_GENERAL) need_mask = true;
+        if (MODE == MODE_GENERAL_SLOW) need_mask = true;
 
         if (!skip) {
 #pragma unroll
@@ -480,12 +594,24 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 // S[q][key], dP[q][key] for 32 rows x KB*32 keys
                 f32x16 sacc[KB], pacc[KB];
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
+                for (int kb = 0; kb < KB; ++kb) {
+                    if (VEC) {
+                        const int cb = wave * KB + kb;   // this wave's 32-key column block inside the additive tile
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        sacc[kb][r] = 0.f;
-                        pacc[kb][r] = 0.f;
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            vec8 av = lds_read_trfrag<E, 128>(tA + (cb >> 2) * (QT * 256), qb * 32 + 16 * t2, cb & 3, lane);
+                            uint16_t ab[8];
+                            __builtin_memcpy(ab, &av, 16);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) sacc[kb][8 * t2 + e] = E::to_f32(ab[e]) * binv;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
                     }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pacc[kb][r] = 0.f;
+                }
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     vec8 qa = lds_read_rowfrag<E, D>(tQ, qb * 32 + l31, s, hi);
@@ -520,7 +646,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                         if (decltype(MASKED)::value) {
                             const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                             show = (key < p.Sk) && (row < p.Sq) && (!causal || key <= row + coff);
-                            if (MODE == MODE_GENERAL) {
+                            if (MODE == MODE_GENERAL_SLOW) {
                                 if (p.bias != nullptr && show) {
                                     const int64_t bo = b * p.bs[0] + h * p.bs[1] + (int64_t)row * p.bs[2] + (int64_t)key * p.bs[3];
                                     float bv;
@@ -534,7 +660,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                                 }
                             }
                         }
-                        float pv = (MODE == MODE_GENERAL) ? fast_exp2(y - lr[r]) : fast_exp2(__builtin_fmaf(sacc[kb][r], p.c, -lr[r]));
+                        float pv = (MODE == MODE_GENERAL_SLOW) ? fast_exp2(y - lr[r]) : fast_exp2(__builtin_fmaf(sacc[kb][r], p.c, -lr[r]));
                         if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                         float dp = pacc[kb][r];
                         float pd = pv;
@@ -583,6 +709,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             tsQ.lstore(stQ, ldsQ + (buf ^ 1) * TILEB);
             tsD.lstore(stD, ldsDO + (buf ^ 1) * TILEB);
             stats_lstore(buf ^ 1);
+            if (VEC) add_lstore(buf ^ 1);
         }
         __syncthreads();
     }

@@ -34,7 +34,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     }
     {   // dK, dV
         constexpr int BN = 4 * KB * 32;
-        constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4;
+        constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (MODE == MODE_GENERAL ? 2 * QT * BN * 2 : 0);
         p.nblk = (p.f.Sk + BN - 1) / BN;
         auto kern = fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP>;
         set_smem(kern, smem);
@@ -49,13 +49,14 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
         switch (mode) {
             case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K, 1>(p, s);
             case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K, 1>(p, s);
-            default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, 1, 1, 1>(p, s);
+            default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1, 1>(p, s);
         }
     }
     switch (mode) {
         case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K>(p, s);
         case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K>(p, s);
-        default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, 1, 1>(p, s);
+        case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1>(p, s);
+        default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, 1, 1>(p, s);   // vector path (bias and/or mask)
     }
 }
 
