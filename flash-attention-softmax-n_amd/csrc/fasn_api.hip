@@ -100,8 +100,10 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
         const int64_t mb = a->mask.ptr ? ((int64_t)(a->Sq - 1) * a->mask.stride[2] + a->Sk) : 0;
         if (bb >= (1ll << 31)) p.bias_vec = 0;
         if (mb >= (1ll << 31)) p.mask_vec = 0;
-        p.bias_bytes = (unsigned)bb;
-        p.mask_bytes = (unsigned)mb;
+        // the range check works on whole dwords: round the extent up so an odd tail (Sk % 2 for bias, Sk % 4 for mask) is
+        // still fetched; the pointer is dword aligned, so the extra bytes share a dword with valid ones and are never used
+        p.bias_bytes = (unsigned)((bb + 3) & ~3ll);
+        p.mask_bytes = (unsigned)((mb + 3) & ~3ll);
     }
     // dropout: 8-bit threshold, drop probability thr/256 (the nearest representable value to dropout_p, at least 1/256)
     p.drop_thr = 0;

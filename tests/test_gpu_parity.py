@@ -189,6 +189,31 @@ def test_mask_bias_combinations(pkg, dev, kind, D, dtype):
         _check(got, want, dtype, f"{kind}/{nm}")
 
 
+@pytest.mark.parametrize("S", [257, 262, 263])
+def test_mask_bias_views_with_odd_key_tails(pkg, dev, S):
+    """mask / bias handed over as views into wider buffers: rows stay aligned (vector loads) while the key count leaves a
+    partial dword at the end of every row - the last keys must still be read"""
+    dtype = torch.bfloat16
+    B, H, L, D, W = 2, 2, 130, 64, 272
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    gen = torch.Generator().manual_seed(11)
+    bias = (2.0 * torch.randn(1, H, L, W, generator=gen)).to(dtype).to(dev)[..., :S]
+    mask = (torch.rand(B, 1, L, W, generator=gen) < 0.6).to(dev)[..., :S]
+    mask[..., S - 1] = True          # the very last key is visible and carries weight
+    bias[..., S - 1] += 3.0
+    assert bias.stride(2) == W and mask.stride(2) == W
+    for m, bb in ((mask, bias), (mask, None), (None, bias)):
+        for t in (q, k, v):
+            t.grad = None
+        out = pkg.flash_attention_n(q, k, v, softmax_n_param=1, attn_mask=m, attn_bias=bb)
+        out.backward(do)
+        o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0, attn_mask=m,
+                                        attn_bias=None if bb is None else bb.float())
+        for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+            _check(got, want, dtype, f"S={S} {nm}")
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 3, 8), (1, 2, 1, 64), (1, 1, 65, 16), (3, 2, 127, 96), (1, 1, 257, 40)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_ragged_and_padded_feature_dims(pkg, dev, shape, causal):
