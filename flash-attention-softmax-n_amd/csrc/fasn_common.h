@@ -124,6 +124,28 @@ FASN_DEV typename E::vec8 lds_read_trfrag(const char* tile, int rbase, int cblk,
     return r;
 }
 
+// 16 bytes per lane straight from a buffer into LDS: LDS byte address = lds_base + 16*lane (lds_base wave-uniform, goes to
+// M0), global address = descriptor base + voff + soff. Written as inline asm on purpose: for the builtin the compiler
+// tracks the LDS write and puts `s_waitcnt vmcnt(0)` in front of later LDS reads it cannot prove disjoint, which would
+// serialise the prefetch; here the caller owns the `s_waitcnt vmcnt(N)` + barrier that publishes the data.
+FASN_DEV void lds_dma16(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory", "m0");
+}
+// raw buffer descriptor (stride 0, range-checked on `bytes`) as four SGPR words
+FASN_DEV u32x4 make_rsrc_words(const void* base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+FASN_DEV uint32_t lds_addr(const void* p) {
+    return (uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(const char, p));
+}
+
 // exchange a value between lane l and lane l^32 and return max(own, partner's)
 FASN_DEV float max_across_halves(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);

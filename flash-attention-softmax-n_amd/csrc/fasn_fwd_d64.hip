@@ -34,10 +34,27 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 40: return launch_fwd_ring<Tag, 64, 2, 2>(p, l.mode, s);
         case 41: return launch_fwd_ring<Tag, 64, 1, 3>(p, l.mode, s);
         case 42: return launch_fwd_ring<Tag, 64, 1, 2>(p, l.mode, s);
+        case 43: return launch_fwd_ring<Tag, 64, 2, 2, 2>(p, l.mode, s);   // direct-to-LDS staging, three tile buffers
+        case 44: return launch_fwd_ring<Tag, 64, 1, 3, 2>(p, l.mode, s);
+        case 45: return launch_fwd_ring<Tag, 64, 1, 2, 2>(p, l.mode, s);
+        case 46: return launch_fwd_ring<Tag, 64, 2, 2, 1, 2>(p, l.mode, s);   // static priority for alternate workgroups
+        case 47: return launch_fwd_ring<Tag, 64, 2, 2, 1, 3>(p, l.mode, s);   // raised priority while issuing QK^T
+        case 48: return launch_fwd_ring<Tag, 64, 1, 3, 1, 2>(p, l.mode, s);
+        case 49: return launch_fwd_ring<Tag, 64, 1, 3, 1, 3>(p, l.mode, s);
         case 50: return launch_fwd_split<Tag, 64, 2, 2>(p, l.mode, s);
         case 51: return launch_fwd_split<Tag, 64, 1, 3>(p, l.mode, s);
         case 52: return launch_fwd_split<Tag, 64, 1, 2>(p, l.mode, s);
         case 5: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 1>(p, l.mode, s);
+        case 60: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 2>(p, l.mode, s);   // pipelined + explicit MFMA/VALU interleave
+        case 61: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 2>(p, l.mode, s);
+        case 62: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 3>(p, l.mode, s);   // hand-ordered block
+        case 63: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 3>(p, l.mode, s);
+        case 64: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 4>(p, l.mode, s);   // ablation: no staging
+        case 65: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 5>(p, l.mode, s);   // ablation: no staging, no barrier
+        case 68: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 6>(p, l.mode, s);   // ablation: + no LDS fragment reads
+        case 69: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 6>(p, l.mode, s);
+        case 66: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 4>(p, l.mode, s);
+        case 67: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 5>(p, l.mode, s);
         case 7: return launch_fwd_pipe_mode<Tag, 64, 2, 1, 1>(p, l.mode, s);
         case 8: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 1>(p, l.mode, s);
         case 4: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 1, 2>(p, l.mode, s); break;

@@ -68,6 +68,9 @@ constexpr float kSumLimit = 256.0f;
 // RING: 1 = two staging register sets, K/V tiles are loaded TWO tiles ahead (the loop body is instantiated twice with the
 // sets swapped). One tile of lead is about 1.2 us at D=64, less than a first-touch HBM miss under load; in-order vmcnt
 // makes any older outstanding load block the wait, so the extra lead has to come from a second register set.
+// RING: 2 = no staging registers at all: `buffer_load_dwordx4 ... lds` moves each 16-byte chunk straight from HBM/L2 into
+// the LDS tile image (LDS address = wave base + 16*lane, so the swizzle is applied by choosing WHICH global chunk a lane
+// fetches), three LDS tile buffers, loads issued two tiles ahead, `s_waitcnt vmcnt` before the barrier that publishes a tile.
 template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0, int RING = 0>
 __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
     using E = ET<Tag>;
@@ -83,8 +86,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     static_assert(NLD >= 1, "tile too small for this workgroup size");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const ldsK = smem;              // [2][TILEB]
-    char* const ldsV = smem + 2 * TILEB;  // [2][TILEB]
+    constexpr int NBUF = RING == 2 ? 3 : 2;
+    char* const ldsK = smem;                 // [NBUF][TILEB]
+    char* const ldsV = smem + NBUF * TILEB;  // [NBUF][TILEB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -154,16 +158,26 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int ci = tid + i * NT;
-        const int row = ci / CPR, ch = ci % CPR;
+        int row = ci / CPR, ch = ci % CPR;
+        if (RING == 2) ch ^= swz_f<D>(row);   // thread `tid` fills LDS slot ci of the image: fetch the chunk that belongs there
         kvoff[i] = (unsigned)(row * (int)p.ks[2] * 2 + ch * 16);
         vvoff[i] = (unsigned)(row * (int)p.vs[2] * 2 + ch * 16);
         ldsoff[i] = tile_off<D>(row, ch);
     }
     const int ktile_bytes = KT * (int)p.ks[2] * 2;
     const int vtile_bytes = KT * (int)p.vs[2] * 2;
-    u32x4 stK[RING + 1][NLD], stV[RING + 1][NLD];
+    u32x4 stK[(RING == 1) + 1][NLD], stV[(RING == 1) + 1][NLD];
     using Set0 = std::integral_constant<int, 0>;
-    using Set1 = std::integral_constant<int, RING>;
+    using Set1 = std::integral_constant<int, (RING == 1)>;
+    const u32x4 krw = make_rsrc_words(kbase, p.kbytes), vrw = make_rsrc_words(vbase, p.vbytes);
+    const uint32_t ldsK_w = lds_addr(ldsK) + wave * 1024, ldsV_w = lds_addr(ldsV) + wave * 1024;
+    auto stage_direct = [&](int t, int buf) {   // RING 2: tile t -> LDS buffer buf, asynchronously (vmcnt)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            lds_dma16(krw, __builtin_amdgcn_readfirstlane(ldsK_w + buf * TILEB + i * NT * 16), kvoff[i], t * ktile_bytes);
+            lds_dma16(vrw, __builtin_amdgcn_readfirstlane(ldsV_w + buf * TILEB + i * NT * 16), vvoff[i], t * vtile_bytes);
+        }
+    };
     auto stage_load = [&](int t, auto SET) {
         constexpr int S_ = decltype(SET)::value;
 #pragma unroll
@@ -243,7 +257,13 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     braw[qb][kb][g] = __builtin_amdgcn_raw_buffer_load_b64(brs, bvo[qb] + (kb * 32 + 8 * g) * 2, t * (KT * 2), 0);
     };
 
-    if (ntiles > 0) {
+    if (RING == 2) {
+        if (ntiles > 0) {
+            stage_direct(0, 0);
+            stage_direct(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile 0 (and Q) landed; tile 1 in flight
+        }
+    } else if (ntiles > 0) {
         stage_load(0, Set0{});
         stage_store(0, Set0{});
         if (RING) stage_load(1, Set1{});   // tile 1 in flight in the second set
@@ -257,6 +277,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // static priority for the second-dispatched half of an 8-wave workgroup (waves w and w+4 share a SIMD): the two
     // co-resident waves stop running their matrix / exponential phases in lock step
     if (PRIO && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(PRIO);
+    // 4-wave workgroups, two per CU: PRIO 2 = static priority for every other workgroup of a CU's first fill (the two waves
+    // that share a SIMD stop contending symmetrically, one runs ahead and their matrix / exponential phases interleave);
+    // PRIO 3 = raised priority while a wave issues its QK^T MFMAs
+    if (PRIO == 2 && NW == 4 && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
 
     // rows of this wave: [qw0, qw0 + QB*32)
     const int wave_first_vis = qw0 + coff;                 // last visible key of the wave's first row
@@ -264,9 +288,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 
     // one K/V tile; LSET = register set that receives the prefetch issued here, SSET = set written to LDS at the end
     auto tile_body = [&](const int t, auto LSET, auto SSET) {
-        const int buf = (ABL == 6 || ABL == 7) ? 0 : (t & 1);
+        const int buf = (ABL == 6 || ABL == 7) ? 0 : (RING == 2 ? t % 3 : (t & 1));
         const int k0 = t * KT;
-        if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
+        if (RING == 2) stage_direct(t + 2, (t + 2) % 3);   // past-the-end tiles are out of range for the descriptor
+        else if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
 
         // wave-uniform tile classification
         bool skip = false;       // no visible element for this wave
@@ -318,6 +343,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = 0.f;
             }
+            if (PRIO == 3 && NW == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -336,6 +362,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     }
                 }
             }
+
+            if (PRIO == 3 && NW == 4) __builtin_amdgcn_s_setprio(0);
 
             // dropout of the 8 weights of (qb, kb, t2): keys k0 + kb*32 + 16*t2 + 4*hi + {0..3} and + 8 + {0..3}
             auto drop8 = [&](f32x8& x, int qb, int kb, int t2) {
@@ -361,6 +389,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 if (!exact) {
                     float rs = 0.f;
                     const float mneg = -m_run[qb];
+                    // two elements per VALU instruction where the ISA has packed fp32 (v_pk_fma_f32 for s*c - m, v_pk_add_f32
+                    // for the row sum: two independent partial sums); the exponential and the mask multiply stay scalar
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 rs2 = {0.f, 0.f};
+                    const f32x2 c2 = {p.c, p.c}, m2 = {mneg, mneg};
                     auto fast = [&](auto HM) {
 #pragma unroll
                         for (int kb = 0; kb < 2; ++kb)
@@ -368,23 +401,26 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             for (int t2 = 0; t2 < 2; ++t2) {
                                 f32x8 x;
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) {
+                                for (int e = 0; e < 8; e += 2) {
                                     const int r = 8 * t2 + e, g = r >> 2, ee = r & 3;
-                                    const float t = __builtin_fmaf(sacc[qb][kb][r], p.c, mneg);
-                                    float pv;
-                                    if (ABL == 1) pv = sacc[qb][kb][r];
-                                    else pv = fast_exp2(t);
+                                    const f32x2 s2 = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
+                                    const f32x2 t = __builtin_elementwise_fma(s2, c2, m2);
+                                    f32x2 pv;
+                                    if (ABL == 1) pv = s2;
+                                    else pv = f32x2{fast_exp2(t[0]), fast_exp2(t[1])};
                                     if (decltype(HM)::value) {
                                         const uint32_t w = mraw[qb][kb][g];  // mask bytes are 0 / 1 (torch.bool)
-                                        const float mf = (float)((w >> (8 * ee)) & 0xffu);  // v_cvt_f32_ubyteN
-                                        pv *= mf;
+                                        pv[0] *= (float)((w >> (8 * ee)) & 0xffu);  // v_cvt_f32_ubyteN
+                                        pv[1] *= (float)((w >> (8 * (ee + 1))) & 0xffu);
                                     }
-                                    x[e] = pv;
-                                    rs += pv;
+                                    x[e] = pv[0];
+                                    x[e + 1] = pv[1];
+                                    rs2 += pv;
                                 }
                                 if (DROP) drop8(x, qb, kb, t2);   // the row sum keeps the undropped weights
                                 pf[qb][kb][t2] = E::cvt8(x);
                             }
+                        rs = rs2[0] + rs2[1];
                     };
                     using T_ = std::true_type;
                     using F_ = std::false_type;
@@ -524,12 +560,15 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         }
 
         if (bias_fold) bias_gload(t + 1);  // next tile's bias (past-the-end reads return 0); newest in the queue
-        if (ABL != 6 && ABL != 7) {
+        if (RING == 2) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile t+1 is in LDS, tile t+2 still in flight
+            __syncthreads();
+        } else if (ABL != 6 && ABL != 7) {
             if (ABL != 8 && (VEC || RING || t + 1 < ntiles)) stage_store(buf ^ 1, SSET);
             if (ABL != 9) __syncthreads();   // ABL 8: barrier only; ABL 9: staging only
         }
     };
-    if (RING) {
+    if (RING == 1) {
         for (int t = 0; t < ntiles; t += 2) {
             tile_body(t, Set0{}, Set1{});       // even tile: tile t+1 sits in set 1, tile t+2 goes to set 0
             if (t + 1 < ntiles) tile_body(t + 1, Set1{}, Set0{});

@@ -182,10 +182,12 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
         constexpr int C = decltype(CSET)::value;
         const int k0 = t * KT;
         // the tiles loaded one iteration ago land in the buffers nobody reads during this iteration
-        storeK(t & 1);   // K(t+2)
-        storeV(t & 1);   // V(t)
-        loadK(t + 3);
-        loadV(t + 1);
+        if (BURST < 4) {   // BURST 4 / 5: timing ablations (no staging / no staging and no barrier), results are not attention
+            storeK(t & 1);   // K(t+2)
+            storeV(t & 1);   // V(t)
+            loadK(t + 3);
+            loadV(t + 1);
+        }
 
         bool need_mask = (k0 + KT > p.Sk);
         if (causal) need_mask = need_mask || ((k0 + KT - 1) > wave_first_vis);
@@ -195,7 +197,81 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
         float lnew[QB];
         bool bad = false;
 
-        if (!need_mask) {
+        if (BURST >= 3 && !need_mask) {
+            // ---- hand-ordered block (QB = 1): 16 groups, each = one MFMA (PV of tile t-1, then QK^T of tile t+1), the LDS
+            // fragment read of the MFMA four groups later, and the softmax arithmetic of two elements per lane of tile t,
+            // skewed over three groups (packed fma | two exponentials | packed add + packed convert) so no instruction
+            // waits on the one in front of it. sched_barrier(0) pins the order: an in-order wave overlaps an MFMA only
+            // with what follows it in program order, and the compiler's own order clusters the MFMAs.
+            static_assert(BURST < 3 || QB == 1, "hand-ordered block is written for QB = 1");
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            constexpr int NF = 4, LEAD = 2;
+            vec8 fr[NF];
+            const f32x2 c2 = {p.c, p.c}, m2 = {-m_run[0], -m_run[0]};
+            f32x2 rs2 = {0.f, 0.f};
+            f32x2 tq[2], xq[2];   // pk_fma results / exponentials in flight, indexed by pair parity
+            auto ds = [&](int j) {
+                if (BURST == 6 || BURST == 7) { fr[j % NF] = qf[0][j & 3]; asm volatile("" : "+v"(fr[j % NF])); return; }   // ablation: no LDS reads
+                if (j < 8) fr[j % NF] = lds_read_trfrag<E, D>(tVp, (j >> 2) * 32 + 16 * ((j >> 1) & 1), j & 1, lane);
+                else fr[j % NF] = lds_read_rowfrag<E, D>(tKn, ((j - 8) & 1) * 32 + l31, (j - 8) >> 1, hi);
+            };
+            auto mm = [&](int j) {
+                if (j < 8) {
+                    oacc[0][j & 1] = E::mfma(fr[j % NF], pf[C ^ 1][0][j >> 2][(j >> 1) & 1], oacc[0][j & 1]);
+                } else {
+                    const int kb = (j - 8) & 1, ks = (j - 8) >> 1;   // alternate the two accumulators
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    sacc[C ^ 1][0][kb] = E::mfma(fr[j % NF], qf[0][ks], ks == 0 ? z : sacc[C ^ 1][0][kb]);
+                }
+            };
+            // pair i = elements (kb = i>>3, r = 2*(i&7), r+1)
+            auto v_fma = [&](int i) {
+                if (i < 0 || i > 15) return;
+                const f32x2 s2 = {sacc[C][0][i >> 3][2 * (i & 7)], sacc[C][0][i >> 3][2 * (i & 7) + 1]};
+                tq[i & 1] = __builtin_elementwise_fma(s2, c2, m2);
+            };
+            auto v_exp = [&](int i) {
+                if (i < 0 || i > 15) return;
+                xq[i & 1] = f32x2{fast_exp2(tq[i & 1][0]), fast_exp2(tq[i & 1][1])};
+            };
+            auto v_out = [&](int i) {
+                if (i < 0 || i > 15) return;
+                rs2 += xq[i & 1];
+                typedef std::remove_reference_t<decltype(vec8{}[0])> el_t;
+                typedef el_t el2_t __attribute__((ext_vector_type(2)));
+                const el2_t h2 = __builtin_convertvector(xq[i & 1], el2_t);
+                const int kb = i >> 3, t2 = (i >> 2) & 1, e = 2 * (i & 3);
+                pf[C][0][kb][t2][e] = h2[0];
+                pf[C][0][kb][t2][e + 1] = h2[1];
+            };
+#pragma unroll
+            for (int j = 0; j < NF; ++j) ds(j);
+            // softmax runs LEAD groups ahead of the MFMAs: it covers the latency of the first fragment reads
+#pragma unroll
+            for (int i = -LEAD; i < 0; ++i) {
+                v_out(i + LEAD - 2);
+                v_exp(i + LEAD - 1);
+                v_fma(i + LEAD);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                mm(i);
+                if (i + NF < 16) ds(i + NF);
+                v_out(i + LEAD - 2);
+                v_exp(i + LEAD - 1);
+                v_fma(i + LEAD);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            v_out(15 + LEAD - 1);   // drain the skew
+            v_exp(15 + LEAD);
+            v_out(15 + LEAD);
+            const float rs = rs2[0] + rs2[1];
+            bad = !(rs <= kSumLimit);
+            lnew[0] = l_run[0] + rs;
+        } else if (!need_mask) {
             // ---- ONE basic block: 16*QB MFMAs (PV of the previous tile, QK^T of the next) + the exponentials of this tile
             if (BURST) {
                 vec8 vfr[2][2][DB], kfr[2][KS];
@@ -237,22 +313,42 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
             }
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                float rs = 0.f;
-                const float mneg = -m_run[qb];
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 rs2 = {0.f, 0.f};
+                const f32x2 c2 = {p.c, p.c}, m2 = {-m_run[qb], -m_run[qb]};
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {
                         f32x8 x;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            x[e] = fast_exp2(__builtin_fmaf(sacc[C][qb][kb][8 * t2 + e], p.c, mneg));
-                            rs += x[e];
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 s2 = {sacc[C][qb][kb][8 * t2 + e], sacc[C][qb][kb][8 * t2 + e + 1]};
+                            const f32x2 t_ = __builtin_elementwise_fma(s2, c2, m2);   // v_pk_fma_f32
+                            const f32x2 pv = {fast_exp2(t_[0]), fast_exp2(t_[1])};
+                            x[e] = pv[0];
+                            x[e + 1] = pv[1];
+                            rs2 += pv;                                                // v_pk_add_f32
                         }
                         pf[C][qb][kb][t2] = E::cvt8(x);
                     }
+                const float rs = rs2[0] + rs2[1];
                 bad = bad || !(rs <= kSumLimit);
                 lnew[qb] = l_run[qb] + rs;
+            }
+            if (BURST == 2) {
+                // instruction order of the block, one group per MFMA: the matrix instruction, the LDS fragment reads of a later
+                // one, then this tile's softmax arithmetic for 2*QB... elements per lane (packed fma / add / convert + exponentials)
+                constexpr int NM = 16 * QB;                    // MFMAs in the block
+                constexpr int NDS = 16 + 2 * KS;               // ds_read_b64_tr (PV) + ds_read_b128 (QK^T)
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < NDS - 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                }
             }
         } else {
             pv_tile(tVp, pf[C ^ 1]);
@@ -305,7 +401,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
         }
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) l_run[qb] = lnew[qb];
-        __syncthreads();
+        if (BURST != 5 && BURST != 6) __syncthreads();
     };
     for (int t = 0; t < ntiles; t += 2) {
         tile_body(t, std::integral_constant<int, 0>{});

@@ -68,20 +68,20 @@ int launch_fwd_abl(FwdParams p, hipStream_t s) {
 }
 
 // plain / causal kernel with two staging register sets (K/V loaded two tiles ahead)
-template <typename Tag, int D, int QB, int MODE, int OCC>
+template <typename Tag, int D, int QB, int MODE, int OCC, int RING = 1, int PRIO = 0>
 int launch_fwd_ring_one(FwdParams p, hipStream_t s) {
     constexpr int BM = 4 * QB * 32;
-    constexpr int smem = 4 * KT * D * 2;
+    constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2;
     p.nqblk = (p.Sq + BM - 1) / BM;
-    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, 4, 0, 0, 0, 1>;
+    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, 4, PRIO, 0, 0, RING>;
     if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
-template <typename Tag, int D, int QB, int OCC>
+template <typename Tag, int D, int QB, int OCC, int RING = 1, int PRIO = 0>
 int launch_fwd_ring(const FwdParams& p, int mode, hipStream_t s) {
-    if (mode == MODE_PLAIN) return launch_fwd_ring_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
-    return launch_fwd_ring_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
+    if (mode == MODE_PLAIN) return launch_fwd_ring_one<Tag, D, QB, MODE_PLAIN, OCC, RING, PRIO>(p, s);
+    return launch_fwd_ring_one<Tag, D, QB, MODE_CAUSAL, OCC, RING, PRIO>(p, s);
 }
 
 // key-block-split kernel (fasn_fwd_split.h)
