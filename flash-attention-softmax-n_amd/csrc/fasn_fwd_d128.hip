@@ -1,4 +1,4 @@
-// D = 128 forward instantiations (QB=1: 128 query rows per workgroup; O^T alone is 64 registers).
+// D = 128 forward instantiations (QB=1: 32 query rows per wave; O^T alone is 64 registers).
 #include "fasn_launch.h"
 namespace fasn {
 template <typename Tag>
@@ -15,6 +15,22 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (p.drop_thr) return launch_fwd_drop<Tag, 128, 1, 1>(p, l.mode, s);
     if (l.mode >= MODE_GENERAL) return launch_gen<Tag>(p, l, s);
     if (l.variant == 1) return launch_fwd_mode<Tag, 128, 1, 1>(p, l.mode, s);
+    // A/B and ablations (tools/fasn_harness bench ... <variant>); ablation results are not attention outputs
+    if (l.variant == 40) return launch_fwd_ring<Tag, 128, 1, 2>(p, l.mode, s);
+    if (l.variant == 43) return launch_fwd_ring<Tag, 128, 1, 2, 2>(p, l.mode, s);
+    if (l.variant == 13) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 0>(p, l.mode, s);   // 8 waves share one K/V tile
+    if (l.variant == 14) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 2>(p, l.mode, s);   // + direct-to-LDS staging
+    if (l.variant == 15) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 1>(p, l.mode, s);
+    if (l.variant == 21) return launch_fwd_abl<Tag, 128, 1, 2, 1>(p, s);
+    if (l.variant == 23) return launch_fwd_abl<Tag, 128, 1, 2, 3>(p, s);
+    if (l.variant == 25) return launch_fwd_abl<Tag, 128, 1, 2, 5>(p, s);
+    if (l.variant == 26) return launch_fwd_abl<Tag, 128, 1, 2, 6>(p, s);
+    if (l.variant == 27) return launch_fwd_abl<Tag, 128, 1, 2, 7>(p, s);
+    // auto: with enough work to give every CU two 256-row blocks, one 8-wave workgroup per CU (eight waves share each staged
+    // K/V tile, tiles loaded two ahead in two register sets) beats two 4-wave workgroups: 1134 vs 1014 TFLOP/s at
+    // (4,32,8192,128) bf16, 886 vs 790 at (2,16,2048,128); staging + barrier cost 26 % of the 4-wave kernel at D = 128
+    const long blocks256 = (long)((p.Sq + 255) / 256) * p.B * p.H;
+    if (l.variant == 0 && blocks256 >= 512) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 1>(p, l.mode, s);
     return launch_fwd_mode<Tag, 128, 1, 2>(p, l.mode, s);
 }
 int launch_fwd_d128(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {

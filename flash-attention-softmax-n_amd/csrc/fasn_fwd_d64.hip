@@ -34,6 +34,9 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 40: return launch_fwd_ring<Tag, 64, 2, 2>(p, l.mode, s);
         case 41: return launch_fwd_ring<Tag, 64, 1, 3>(p, l.mode, s);
         case 42: return launch_fwd_ring<Tag, 64, 1, 2>(p, l.mode, s);
+        case 17: return launch_fwd_cfg<Tag, 64, 2, 2, 8, 1>(p, l.mode, s);   // 8 waves share a K/V tile, two-set ring
+        case 18: return launch_fwd_cfg<Tag, 64, 2, 2, 8, 2>(p, l.mode, s);   // 8 waves, direct-to-LDS
+        case 19: return launch_fwd_cfg<Tag, 64, 1, 3, 8, 1>(p, l.mode, s);
         case 43: return launch_fwd_ring<Tag, 64, 2, 2, 2>(p, l.mode, s);   // direct-to-LDS staging, three tile buffers
         case 44: return launch_fwd_ring<Tag, 64, 1, 3, 2>(p, l.mode, s);
         case 45: return launch_fwd_ring<Tag, 64, 1, 2, 2>(p, l.mode, s);

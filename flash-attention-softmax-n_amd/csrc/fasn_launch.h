@@ -21,6 +21,11 @@ int launch_fwd_d64(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_fwd_d128(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 
 
+template <typename K>
+inline void set_smem_attr(K kern, int smem) {
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
 template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4>
 int launch_fwd_one(FwdParams p, hipStream_t s) {
     constexpr int BM = NW * QB * 32;
@@ -144,6 +149,25 @@ template <typename Tag, int D, int OCC>
 int launch_fwd_pp_mode(const FwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_PLAIN) return launch_fwd_pp_one<Tag, D, MODE_PLAIN, OCC>(p, s);
     return launch_fwd_pp_one<Tag, D, MODE_CAUSAL, OCC>(p, s);
+}
+
+// any (workgroup size, staging scheme) combination of the plain / causal kernel
+template <typename Tag, int D, int QB, int OCC, int NW, int RING>
+int launch_fwd_cfg(FwdParams p, int mode, hipStream_t s) {
+    constexpr int BM = NW * QB * 32;
+    constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2;
+    p.nqblk = (p.Sq + BM - 1) / BM;
+    const dim3 grid((unsigned)(p.nqblk * p.B * p.H)), block(NW * 64);
+    if (mode == MODE_PLAIN) {
+        auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_PLAIN, OCC, NW, 0, 0, 0, RING>;
+        set_smem_attr(kern, smem);
+        hipLaunchKernelGGL(kern, grid, block, smem, s, p);
+    } else {
+        auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_CAUSAL, OCC, NW, 0, 0, 0, RING>;
+        set_smem_attr(kern, smem);
+        hipLaunchKernelGGL(kern, grid, block, smem, s, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
 // pipelined kernel for plain / causal; the general (mask / bias) mode stays on fasn_fwd_kernel
