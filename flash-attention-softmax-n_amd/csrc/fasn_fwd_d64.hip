@@ -4,6 +4,10 @@
 namespace fasn {
 template <typename Tag>
 static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (l.variant == 70) return launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 2>(p, s);          // A/B: 64 rows per wave
+    if (l.variant == 71) return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 8>(p, s);       // A/B: 8 waves
+    if (l.variant == 72) return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 4, 2>(p, s);    // A/B: direct K/V staging
+    if (l.variant == 73) return launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 2, 4, 2>(p, s);
     switch (l.mode) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2>(p, s);
         case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_B, 2>(p, s);

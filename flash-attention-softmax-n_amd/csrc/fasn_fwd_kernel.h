@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     constexpr bool GEN = VEC || SLOW;
     constexpr bool VBIAS = MODE == MODE_GENERAL || MODE == MODE_GENERAL_B;   // vector bias present (compile time)
     constexpr bool VMASK = MODE == MODE_GENERAL || MODE == MODE_GENERAL_M;   // vector mask present (compile time)
+    constexpr bool KPERM = VEC;
     if (GEN && p.batch_inner && (p.H & 7) == 0) {
         // per XCD: (head, q-block, batch) with the batch fastest -> the B workgroups that read the same bias tile run together
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -160,8 +161,12 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         const int ci = tid + i * NT;
         int row = ci / CPR, ch = ci % CPR;
         if (RING == 2) ch ^= swz_f<D>(row);   // thread `tid` fills LDS slot ci of the image: fetch the chunk that belongs there
-        kvoff[i] = (unsigned)(row * (int)p.ks[2] * 2 + ch * 16);
-        vvoff[i] = (unsigned)(row * (int)p.vs[2] * 2 + ch * 16);
+        // vector general modes: LDS row rho of a 32-row block holds key kperm(rho), so that the accumulator registers of a
+        // lane (MFMA rows (r&3) + 8(r>>2) + 4hi) are the 16 CONSECUTIVE keys 16hi + r: bias / mask rows are then read
+        // 32 / 16 contiguous bytes per lane. K and V use the same order, the PV contraction does not see it.
+        const int grow = KPERM ? ((row & ~31) | (((row >> 2) & 1) << 4) | (((row >> 3) & 3) << 2) | (row & 3)) : row;
+        kvoff[i] = (unsigned)(grow * (int)p.ks[2] * 2 + ch * 16);
+        vvoff[i] = (unsigned)(grow * (int)p.vs[2] * 2 + ch * 16);
         ldsoff[i] = tile_off<D>(row, ch);
     }
     const int ktile_bytes = KT * (int)p.ks[2] * 2;
@@ -214,8 +219,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     //       instead of faulting; reads past Sk elsewhere return in-range garbage that the visibility select discards) and
     //       a per-lane byte offset of this lane's row + its 4*hi keys; 4 keys per load.
     // SLOW: per-lane row pointers, one element per load.
-    __amdgpu_buffer_rsrc_t brs, mrs;
-    unsigned bvo[QB], mvo[QB];
+    u32x4 brw, mrw;
+    unsigned bvo[QB][4], mvo[QB][2];
     const char* bptr[QB];
     const uint8_t* mptr[QB];
     const bool has_bias = VBIAS || (SLOW && p.bias != nullptr);
@@ -225,8 +230,17 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         for (int qb = 0; qb < QB; ++qb) {
             const int rowc = min(qw0 + qb * 32 + l31, p.Sq - 1);
             if (VEC) {
-                bvo[qb] = (unsigned)((rowc * p.bs[2] + 4 * hi) * 2);
-                mvo[qb] = (unsigned)(rowc * p.ms[2] + 4 * hi);
+                // slot s = 64*i + lane of the wave's LDS image <- the 16-byte chunk that belongs there (swizzled like the K/V tiles)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sl = i * 64 + lane, row = sl >> 3, c = (sl & 7) ^ swz_f<64>(row);
+                    bvo[qb][i] = (unsigned)(((qw0 + qb * 32 + row) * (int)p.bs[2] + c * 8) * 2);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int sl = i * 64 + lane, row = sl >> 2, c = (sl & 3) ^ swz_f<32>(row);
+                    mvo[qb][i] = (unsigned)((qw0 + qb * 32 + row) * (int)p.ms[2] + c * 16);
+                }
             } else {
                 const int esz = p.bias_f32 ? 4 : 2;
                 bptr[qb] = has_bias ? p.bias + (b * p.bs[0] + h * p.bs[1] + (int64_t)rowc * p.bs[2] + 4 * hi * p.bs[3]) * esz : nullptr;
@@ -236,29 +250,42 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         if (VEC) {
             const char* bb = has_bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
             const char* mb = has_mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
-            brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bb), 0, has_bias ? p.bias_bytes : 0u, 0x00020000);
-            mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mb), 0, has_mask ? p.mask_bytes : 0u, 0x00020000);
+            brw = make_rsrc_words(bb, has_bias ? p.bias_bytes : 0u);
+            mrw = make_rsrc_words(mb, has_mask ? p.mask_bytes : 0u);
         }
     }
+    // VEC: bias / mask of the wave's own 32*QB rows x 64 keys go HBM -> LDS with coalesced 16-byte `buffer_load ... lds`
+    // (8 / 4 lanes cover one row's 128 / 64 bytes; a lane-per-row register load would touch 32 cache lines per instruction
+    // and made the texture addresser the bottleneck), into a wave-private image next to the K/V tiles; the lane then reads
+    // its row's 32 + 16 bytes per 32-key block with ds_read_b128. Single-buffered: tile t+1 is requested right after
+    // tile t has been read into registers, and lands while tile t is computed.
+    char* const ldsGB = smem + 2 * NBUF * TILEB + wave * (QB * 6144);   // [QB][32 rows][128 B] bias
+    char* const ldsGM = ldsGB + QB * 4096;                                // [QB][32 rows][64 B] mask
+    const uint32_t ldsGB_a = lds_addr(ldsGB), ldsGM_a = lds_addr(ldsGM);
+    auto gen_dma = [&](int t) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (VBIAS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds_dma16(brw, __builtin_amdgcn_readfirstlane(ldsGB_a + qb * 4096 + i * 1024), bvo[qb][i], t * (KT * 2));
+            }
+            if (VMASK) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) lds_dma16(mrw, __builtin_amdgcn_readfirstlane(ldsGM_a + qb * 2048 + i * 1024), mvo[qb][i], t * KT);
+            }
+        }
+    };
 
     // VEC, bias present: the bias is folded into the QK^T accumulator INITIAL value (S' = bias*log2e/c + q.k, y = c*S'),
     // so the softmax below is the plain one and no bias register outlives the MFMAs. A lane's pieces for the NEXT tile
     // are loaded while the PV MFMAs of the current tile run.
-    u32x2 braw[QB][2][4];
+    // MODE_GENERAL launched without a mask (bias only, where the bias-only instantiation is the worse kernel): every byte reads as set
+    const uint32_t nomask = (VMASK && p.mask == nullptr) ? 0x01010101u : 0u;
     constexpr bool bias_fold = VBIAS;
     const float binv = bias_fold ? kLog2e / p.c : 0.f;
-    auto bias_gload = [&](int t) {
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    braw[qb][kb][g] = __builtin_amdgcn_raw_buffer_load_b64(brs, bvo[qb] + (kb * 32 + 8 * g) * 2, t * (KT * 2), 0);
-    };
-
     if (RING == 2) {
         if (ntiles > 0) {
+            if (VEC) gen_dma(0);
             stage_direct(0, 0);
             stage_direct(1, 1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile 0 (and Q) landed; tile 1 in flight
@@ -267,7 +294,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         stage_load(0, Set0{});
         stage_store(0, Set0{});
         if (RING) stage_load(1, Set1{});   // tile 1 in flight in the second set
-        if (bias_fold) bias_gload(0);
+        if (VEC) gen_dma(0);
     }
     __syncthreads();
 #pragma unroll
@@ -290,7 +317,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     auto tile_body = [&](const int t, auto LSET, auto SSET) {
         const int buf = (ABL == 6 || ABL == 7) ? 0 : (RING == 2 ? t % 3 : (t & 1));
         const int k0 = t * KT;
-        if (RING == 2) stage_direct(t + 2, (t + 2) % 3);   // past-the-end tiles are out of range for the descriptor
+        if (RING == 2 && !VEC) stage_direct(t + 2, (t + 2) % 3);   // past-the-end tiles are out of range for the descriptor
         else if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
 
         // wave-uniform tile classification
@@ -304,36 +331,57 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 
         // VEC: mask bytes of this lane's elements, 4 consecutive keys per load; SLOW: every tile takes the exact path
         uint32_t mraw[QB][2][4];
-        constexpr bool bvec = VBIAS;            // this tile's bias sits in braw (loaded during the previous tile)
-        constexpr bool mvec = VMASK;
+        u32x2 braw[QB][2][4];
         if (SLOW) need_mask = true;
-        if (mvec) {   // unconditional (also for skipped tiles) and ahead of the K/V prefetch: in-order vmcnt stays countable
+        if (VEC) {   // unconditional (also for skipped tiles): the request / wait pattern stays the same for every tile
+            // this tile's bias / mask image has landed (RING 2: the K/V tile requested last stays in flight)
+            if (RING == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (VBIAS) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        mraw[qb][kb][g] = __builtin_amdgcn_raw_buffer_load_b32(mrs, mvo[qb] + kb * 32 + 8 * g, k0, 0);
+                        for (int j = 0; j < 2; ++j) {
+                            const u32x4 w = *LDS_PTR(const u32x4, ldsGB + qb * 4096 + tile_off<64>(l31, kb * 4 + 2 * hi + j));
+                            braw[qb][kb][2 * j] = u32x2{w[0], w[1]};
+                            braw[qb][kb][2 * j + 1] = u32x2{w[2], w[3]};
+                        }
+                    }
+                    if (VMASK) {
+                        const u32x4 w = *LDS_PTR(const u32x4, ldsGM + qb * 2048 + tile_off<32>(l31, kb * 2 + hi));
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) mraw[qb][kb][g] = w[g];
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before the next one is requested
+            gen_dma(t + 1);                                        // past-the-end tiles are out of range: zeros
+            if (RING == 2) stage_direct(t + 2, (t + 2) % 3);
+            else stage_load(t + 1 + RING, LSET);
         }
-        if (VMASK) __builtin_amdgcn_sched_barrier(0);  // keep the mask loads OLDER than the K/V prefetch in the vmcnt queue
-        if (VEC) stage_load(t + 1 + RING, LSET);   // past-the-end tiles read back as zeros
-        if (VMASK) __builtin_amdgcn_sched_barrier(0);
         if (!skip) {
             const char* tK = ldsK + buf * TILEB;
             const char* tV = ldsV + buf * TILEB;
 
             // ---- S^T = K Q^T : acc[qb][kb], 32 keys x 32 queries each
             f32x16 sacc[QB][2];
-            if (bvec) {
+            if (VEC) {
+                // S' starts from the additive term: bias*log2e/c where the mask byte is set, -inf where it is clear
+                // (S' = add + q.k, y = c*S'): from here on the tile is handled exactly like a plain one
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
-                            sacc[qb][kb][r] = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * binv;
+                            float v = 0.f;
+                            if (VBIAS) {
+                                const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
+                                v = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * binv;
+                            }
+                            if (VMASK) v = (((mraw[qb][kb][r >> 2] | nomask) >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
+                            sacc[qb][kb][r] = v;
                         }
             } else {
 #pragma unroll
@@ -343,7 +391,6 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = 0.f;
             }
-            if (PRIO == 3 && NW == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -402,17 +449,12 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                                 f32x8 x;
 #pragma unroll
                                 for (int e = 0; e < 8; e += 2) {
-                                    const int r = 8 * t2 + e, g = r >> 2, ee = r & 3;
+                                    const int r = 8 * t2 + e;
                                     const f32x2 s2 = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
                                     const f32x2 t = __builtin_elementwise_fma(s2, c2, m2);
                                     f32x2 pv;
                                     if (ABL == 1) pv = s2;
                                     else pv = f32x2{fast_exp2(t[0]), fast_exp2(t[1])};
-                                    if (decltype(HM)::value) {
-                                        const uint32_t w = mraw[qb][kb][g];  // mask bytes are 0 / 1 (torch.bool)
-                                        pv[0] *= (float)((w >> (8 * ee)) & 0xffu);  // v_cvt_f32_ubyteN
-                                        pv[1] *= (float)((w >> (8 * (ee + 1))) & 0xffu);
-                                    }
                                     x[e] = pv[0];
                                     x[e + 1] = pv[1];
                                     rs2 += pv;
@@ -424,8 +466,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     };
                     using T_ = std::true_type;
                     using F_ = std::false_type;
-                    if (VMASK) fast(T_{});
-                    else fast(F_{});
+                    fast(F_{});
                     if (ABL == 0 && __any(!(rs <= kSumLimit))) exact = true;
                     else l_run[qb] += rs;
                 }
@@ -433,13 +474,13 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     const int row = qw0 + qb * 32 + l31;
                     const int vis = causal ? (row + coff) : 0x7fffffff;  // last visible key of this row
                     float mx = -INFINITY;
-                    if (!GEN) {
-                        // plain / causal: hide by key range and the causal limit only
+                    if (!SLOW) {
+                        // plain / causal / vector general (mask already folded into S'): hide by key range and the causal limit
 #pragma unroll
                         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                const int key = k0 + kb * 32 + (KPERM ? 16 * hi + r : (r & 3) + 8 * (r >> 2) + 4 * hi);
                                 const bool show = (key < p.Sk) && (key <= vis);
                                 const float y = show ? sacc[qb][kb][r] * p.c : -INFINITY;
                                 sacc[qb][kb][r] = y;
@@ -475,17 +516,6 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                             if ((key < p.Sk) && (key <= vis)) showbits |= 1u << (kb * 16 + r);
                         }
-                    if (mvec) {
-#pragma unroll
-                        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const uint32_t w = mraw[qb][kb][g];
-                                const uint32_t nz = ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) |
-                                                    ((w & 0xff000000u) ? 8u : 0u);
-                                showbits &= ~(0xfu << (kb * 16 + 4 * g)) | (nz << (kb * 16 + 4 * g));
-                            }
-                    }
                     if (SLOW && has_mask) {
 #pragma unroll
                         for (int kb = 0; kb < 2; ++kb)
@@ -559,7 +589,6 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     }
         }
 
-        if (bias_fold) bias_gload(t + 1);  // next tile's bias (past-the-end reads return 0); newest in the queue
         if (RING == 2) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile t+1 is in LDS, tile t+2 still in flight
             __syncthreads();
