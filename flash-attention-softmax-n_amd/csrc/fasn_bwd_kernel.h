@@ -72,13 +72,15 @@ template <int D, int NLD>
 struct TileStage {
     unsigned voff[NLD];
     int loff[NLD];
-    FASN_DEV void init(int tid, int64_t row_stride) {
+    // kperm: LDS row rho of a 32-row block receives global row (key) kperm(rho), see fasn_fwd_kernel.h (vector general modes)
+    FASN_DEV void init(int tid, int64_t row_stride, bool kperm = false) {
         constexpr int CPR = D / 8;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int ci = tid + i * 256;
             const int row = ci / CPR, ch = ci % CPR;
-            voff[i] = (unsigned)(row * (int)row_stride * 2 + ch * 16);
+            const int grow = kperm ? ((row & ~31) | (((row >> 2) & 1) << 4) | (((row >> 3) & 3) << 2) | (row & 3)) : row;
+            voff[i] = (unsigned)(grow * (int)row_stride * 2 + ch * 16);
             loff[i] = tile_off<D>(row, ch);
         }
     }
@@ -90,6 +92,28 @@ struct TileStage {
     FASN_DEV void lstore(const u32x4 (&st)[NLD], char* tile) const {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) *LDS_PTR(u32x4, tile + loff[i]) = st[i];
+    }
+};
+
+// The same tile image filled straight from HBM/L2 (`buffer_load_dwordx4 ... lds`, no staging registers): thread `tid`
+// owns LDS slots tid + 256*i and fetches the 16-byte chunk the swizzle assigns to each. The caller waits (vmcnt) and
+// barriers before the tile is read.
+template <int D, int NLD>
+struct TileDma {
+    unsigned voff[NLD];
+    FASN_DEV void init(int tid, int64_t row_stride) {
+        constexpr int CPR = D / 8;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ci = tid + i * 256;
+            const int row = ci / CPR, ch = (ci % CPR) ^ swz_f<D>(row);
+            voff[i] = (unsigned)(row * (int)row_stride * 2 + ch * 16);
+        }
+    }
+    FASN_DEV void dma(u32x4 rw, uint32_t tile_addr_wave, int row0, int64_t row_stride) const {
+        const int soff = row0 * (int)row_stride * 2;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) lds_dma16(rw, __builtin_amdgcn_readfirstlane(tile_addr_wave + i * 4096), voff[i], soff);
     }
 };
 
@@ -171,8 +195,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase), 0, p.kbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase), 0, p.vbytes, 0x00020000);
     TileStage<D, NLD> tsK, tsV;
-    tsK.init(tid, p.ks[2]);
-    tsV.init(tid, p.vs[2]);
+    tsK.init(tid, p.ks[2], MODE == MODE_GENERAL);
+    tsV.init(tid, p.vs[2], MODE == MODE_GENERAL);
     if (ntiles > 0) {
         tsK.gload(stK, krs, 0, p.ks[2]);
         tsV.gload(stV, vrs, 0, p.vs[2]);
@@ -191,36 +215,47 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         retire_loads(dlt[qb]);
     }
 
-    // MODE_GENERAL (vector path, same scheme as the forward): per-(b,h) buffer descriptors for bias / mask, 4 keys per load,
-    // the bias folded into the S accumulator's initial value (S' = bias*log2e/c + q.k), the 0/1 mask bytes multiplied
-    // into P. An absent operand gets a zero-range descriptor (bias reads 0) / an all-ones OR word (mask keeps everything).
+    // MODE_GENERAL (vector path, same scheme as the forward): K/V rows staged in key-permuted order so a lane's 16
+    // accumulator registers of a 32-key block are 16 consecutive keys; the wave's bias / mask image of each tile goes
+    // HBM -> LDS with coalesced `buffer_load ... lds` and is read back 32 / 16 bytes per lane; the additive term
+    // (bias*log2e/c, or -inf where the mask byte is clear) is the S accumulator's start value. An absent operand gets a
+    // zero-range descriptor (bias reads 0) / an all-ones OR word (mask keeps everything).
     constexpr bool VEC = MODE == MODE_GENERAL;
-    __amdgpu_buffer_rsrc_t brs, mrs;
-    unsigned bvo[QB], mvo[QB];
-    u32x2 braw[QB][2][4];
+    u32x4 brw, mrw;
+    unsigned bvo[QB][4], mvo[QB][2];
     const uint32_t nomask = (VEC && p.mask == nullptr) ? 0x01010101u : 0u;
-    const float binv = (VEC && p.bias != nullptr) ? kLog2e / p.c : 0.f;
-    auto bias_gload = [&](int t) {
+    const float binv = VEC ? kLog2e / p.c : 0.f;
+    char* const ldsGB = smem + 4 * TILEB + wave * (QB * 6144);
+    char* const ldsGM = ldsGB + QB * 4096;
+    const uint32_t ldsGB_a = lds_addr(ldsGB), ldsGM_a = lds_addr(ldsGM);
+    auto gen_dma = [&](int t) {
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
+        for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int i = 0; i < 4; ++i) lds_dma16(brw, __builtin_amdgcn_readfirstlane(ldsGB_a + qb * 4096 + i * 1024), bvo[qb][i], t * (KT * 2));
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    braw[qb][kb][g] = __builtin_amdgcn_raw_buffer_load_b64(brs, bvo[qb] + (kb * 32 + 8 * g) * 2, t * (KT * 2), 0);
+            for (int i = 0; i < 2; ++i) lds_dma16(mrw, __builtin_amdgcn_readfirstlane(ldsGM_a + qb * 2048 + i * 1024), mvo[qb][i], t * KT);
+        }
     };
     if (VEC) {
         const char* bb = p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
         const char* mb = p.mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
-        brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bb), 0, p.bias ? p.bias_bytes : 0u, 0x00020000);
-        mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mb), 0, p.mask ? p.mask_bytes : 0u, 0x00020000);
+        brw = make_rsrc_words(bb, p.bias ? p.bias_bytes : 0u);
+        mrw = make_rsrc_words(mb, p.mask ? p.mask_bytes : 0u);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            const int rowc = min(qw0 + qb * 32 + l31, p.Sq - 1);
-            bvo[qb] = (unsigned)((rowc * p.bs[2] + 4 * hi) * 2);
-            mvo[qb] = (unsigned)(rowc * p.ms[2] + 4 * hi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sl = i * 64 + lane, row = sl >> 3, c = (sl & 7) ^ swz_f<64>(row);
+                bvo[qb][i] = (unsigned)(((qw0 + qb * 32 + row) * (int)p.bs[2] + c * 8) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int sl = i * 64 + lane, row = sl >> 2, c = (sl & 3) ^ swz_f<32>(row);
+                mvo[qb][i] = (unsigned)((qw0 + qb * 32 + row) * (int)p.ms[2] + c * 16);
+            }
         }
-        bias_gload(0);
+        gen_dma(0);
     }
 
     const int wave_first_vis = qw0 + coff;
@@ -230,18 +265,27 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         const int buf = t & 1;
         const int k0 = t * KT;
         uint32_t mraw[QB][2][4];
-        if (VEC) {   // unconditional and older than the K/V prefetch in the vmcnt queue
+        u32x2 braw[QB][2][4];
+        if (VEC) {   // unconditional, also for skipped tiles: the request / wait pattern is the same for every tile
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's image has landed
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        mraw[qb][kb][g] = __builtin_amdgcn_raw_buffer_load_b32(mrs, mvo[qb] + kb * 32 + 8 * g, k0, 0) | nomask;
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < 2; ++j) {
+                        const u32x4 w = *LDS_PTR(const u32x4, ldsGB + qb * 4096 + tile_off<64>(l31, kb * 4 + 2 * hi + j));
+                        braw[qb][kb][2 * j] = u32x2{w[0], w[1]};
+                        braw[qb][kb][2 * j + 1] = u32x2{w[2], w[3]};
+                    }
+                    const u32x4 w = *LDS_PTR(const u32x4, ldsGM + qb * 2048 + tile_off<32>(l31, kb * 2 + hi));
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mraw[qb][kb][g] = w[g] | nomask;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gen_dma(t + 1);                          // past-the-end tiles are out of range: zeros
             tsK.gload(stK, krs, k0 + KT, p.ks[2]);   // past-the-end tiles read back as zeros
             tsV.gload(stV, vrs, k0 + KT, p.vs[2]);
-            __builtin_amdgcn_sched_barrier(0);
         } else if (t + 1 < ntiles) {
             tsK.gload(stK, krs, k0 + KT, p.ks[2]);
             tsV.gload(stV, vrs, k0 + KT, p.vs[2]);
@@ -266,7 +310,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                     for (int r = 0; r < 16; ++r) {
                         if (VEC) {
                             const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
-                            sacc[qb][kb][r] = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * binv;
+                            const float v = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * binv;
+                            sacc[qb][kb][r] = ((mraw[qb][kb][r >> 2] >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
                         } else {
                             sacc[qb][kb][r] = 0.f;
                         }
@@ -298,7 +343,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                         float y = sacc[qb][kb][r] * p.c;
                         bool show = true;
                         if (decltype(MASKED)::value) {
-                            const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const int key = k0 + kb * 32 + (VEC ? 16 * hi + r : (r & 3) + 8 * (r >> 2) + 4 * hi);
                             show = (key < p.Sk) && (key <= vis);
                             if (MODE == MODE_GENERAL_SLOW) {
                                 const bool inb = show && (row < p.Sq);
@@ -316,7 +361,6 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                             }
                         }
                         float pv = (MODE == MODE_GENERAL_SLOW) ? fast_exp2(y - lse2[qb]) : fast_exp2(__builtin_fmaf(sacc[qb][kb][r], p.c, -lse2[qb]));
-                        if (VEC) pv *= (float)((mraw[qb][kb][r >> 2] >> (8 * (r & 3))) & 0xffu);
                         if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                         float dp = pacc[qb][kb][r];
                         if (DROP) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
@@ -351,7 +395,6 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                         for (int qb = 0; qb < QB; ++qb) dqacc[qb][d] = E::mfma(ktf, dsf[qb][kb][t2], dqacc[qb][d]);
                     }
         }
-        if (VEC) bias_gload(t + 1);   // newest entry of the vmcnt queue; lands during the next tile's prologue
         if (VEC || t + 1 < ntiles) {
             tsK.lstore(stK, ldsK + (buf ^ 1) * TILEB);
             tsV.lstore(stV, ldsV + (buf ^ 1) * TILEB);
@@ -467,6 +510,15 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     TileStage<D, NLD> tsQ, tsD;
     tsQ.init(tid, p.qs[2]);
     tsD.init(tid, bp.dos[2]);
+    // vector general mode: Q / dO tiles go straight to LDS (the staging registers are needed for the additive tile)
+    constexpr bool DIRECT = MODE == MODE_GENERAL;
+    TileDma<D, NLD> tdQ, tdD;
+    const u32x4 qrw = make_rsrc_words(qbase, bp.qbytes), drw = make_rsrc_words(dobase, bp.dobytes);
+    const uint32_t ldsQ_w = lds_addr(smem) + wave * 1024, ldsDO_w = ldsQ_w + 2 * TILEB;
+    if (DIRECT) {
+        tdQ.init(tid, p.qs[2]);
+        tdD.init(tid, bp.dos[2]);
+    }
     float stL = 0.f, stX = 0.f;
     auto stats_gload = [&](int row0) {
         if (tid < QT) {
@@ -488,11 +540,18 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     };
 
     if (tq0 < ntq) {
-        tsQ.gload(stQ, qrs, tq0 * QT, p.qs[2]);
-        tsD.gload(stD, drs, tq0 * QT, bp.dos[2]);
+        if (DIRECT) {
+            tdQ.dma(qrw, ldsQ_w, tq0 * QT, p.qs[2]);
+            tdD.dma(drw, ldsDO_w, tq0 * QT, bp.dos[2]);
+        } else {
+            tsQ.gload(stQ, qrs, tq0 * QT, p.qs[2]);
+            tsD.gload(stD, drs, tq0 * QT, bp.dos[2]);
+        }
         stats_gload(tq0 * QT);
-        tsQ.lstore(stQ, ldsQ);
-        tsD.lstore(stD, ldsDO);
+        if (!DIRECT) {
+            tsQ.lstore(stQ, ldsQ);
+            tsD.lstore(stD, ldsDO);
+        }
         stats_lstore(0);
     }
 
@@ -508,8 +567,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     constexpr int ACH = (QT * BN_ / 8) / 256;       // 8-key chunks per thread
     char* const ldsAdd = smem + 4 * TILEB + 4 * QT * 4;   // [2][ADDB]
     __amdgpu_buffer_rsrc_t brs, mrs;
-    unsigned abvo[ACH], amvo[ACH];
-    int aloff[ACH];
+    unsigned abvo0 = 0, amvo0 = 0;   // chunk 0 of this thread; chunk i is RSTEP rows further down (wave-uniform offset)
+    constexpr int RSTEP = 256 / (BN_ / 8);
+    const int arow0 = tid / (BN_ / 8), akc = tid % (BN_ / 8);
     u32x4 stA[ACH];
     u32x2 stM[ACH];
     const uint32_t nomask = (VEC && p.mask == nullptr) ? 0x01010101u : 0u;
@@ -520,21 +580,15 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         const char* mb = p.mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
         brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bb), 0, p.bias ? p.bias_bytes : 0u, 0x00020000);
         mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mb), 0, p.mask ? p.mask_bytes : 0u, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            const int ci = tid + i * 256;
-            const int row = ci / (BN_ / 8), kc = ci % (BN_ / 8);
-            abvo[i] = (unsigned)((row * p.bs[2] + kc * 8) * 2);
-            amvo[i] = (unsigned)(row * p.ms[2] + kc * 8);
-            aloff[i] = (kc >> 4) * (QT * 256) + tile_off<128>(row, kc & 15);
-        }
+        abvo0 = (unsigned)((arow0 * p.bs[2] + akc * 8) * 2);
+        amvo0 = (unsigned)(arow0 * p.ms[2] + akc * 8);
     }
     auto add_gload = [&](int row0) {
         const int kcol0 = kblk * BN_;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            stA[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, abvo[i], (row0 * (int)p.bs[2] + kcol0) * 2, 0);
-            stM[i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, amvo[i], row0 * (int)p.ms[2] + kcol0, 0);
+            stA[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, abvo0, ((row0 + i * RSTEP) * (int)p.bs[2] + kcol0) * 2, 0);
+            stM[i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, amvo0, (row0 + i * RSTEP) * (int)p.ms[2] + kcol0, 0);
         }
     };
     auto add_lstore = [&](int buf) {
@@ -548,13 +602,14 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 const uint32_t hi16 = (mw & 0xff00u) ? (stA[i][w] >> 16) : ninf16;
                 o[w] = lo | (hi16 << 16);
             }
-            *LDS_PTR(u32x4, ldsAdd + buf * ADDB + aloff[i]) = o;
+            *LDS_PTR(u32x4, ldsAdd + buf * ADDB + (akc >> 4) * (QT * 256) + tile_off<128>(arow0 + i * RSTEP, akc & 15)) = o;
         }
     };
     if (VEC && tq0 < ntq) {
         add_gload(tq0 * QT);
         add_lstore(0);
     }
+    if (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
@@ -568,8 +623,13 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         const int buf = (tq - tq0) & 1;
         const int r0 = tq * QT;
         if (tq + 1 < ntq) {
-            tsQ.gload(stQ, qrs, r0 + QT, p.qs[2]);
-            tsD.gload(stD, drs, r0 + QT, bp.dos[2]);
+            if (DIRECT) {   // buffer buf^1 was released by the barrier that ended the previous tile
+                tdQ.dma(qrw, ldsQ_w + (buf ^ 1) * TILEB, r0 + QT, p.qs[2]);
+                tdD.dma(drw, ldsDO_w + (buf ^ 1) * TILEB, r0 + QT, bp.dos[2]);
+            } else {
+                tsQ.gload(stQ, qrs, r0 + QT, p.qs[2]);
+                tsD.gload(stD, drs, r0 + QT, bp.dos[2]);
+            }
             stats_gload(r0 + QT);
             if (VEC) add_gload(r0 + QT);
         }
@@ -706,11 +766,14 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             }
         }
         if (tq + 1 < ntq) {
-            tsQ.lstore(stQ, ldsQ + (buf ^ 1) * TILEB);
-            tsD.lstore(stD, ldsDO + (buf ^ 1) * TILEB);
+            if (!DIRECT) {
+                tsQ.lstore(stQ, ldsQ + (buf ^ 1) * TILEB);
+                tsD.lstore(stD, ldsDO + (buf ^ 1) * TILEB);
+            }
             stats_lstore(buf ^ 1);
             if (VEC) add_lstore(buf ^ 1);
         }
+        if (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next Q / dO tiles have landed
         __syncthreads();
     }
 

@@ -26,7 +26,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     }
     {   // dQ
         constexpr int BM = 4 * QB * 32;
-        constexpr int smem = 4 * KT * D * 2;
+        constexpr int smem = 4 * KT * D * 2 + (MODE == MODE_GENERAL ? 4 * QB * 6144 : 0);   // + per-wave bias / mask images
         p.nblk = (p.f.Sq + BM - 1) / BM;
         auto kern = fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q, DROP>;
         set_smem(kern, smem);
@@ -56,7 +56,7 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
         case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K>(p, s);
         case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K>(p, s);
         case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1>(p, s);
-        default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, 1, 1>(p, s);   // vector path (bias and/or mask)
+        default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1)>(p, s);   // vector path (bias and/or mask)
     }
 }
 
