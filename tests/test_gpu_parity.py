@@ -214,6 +214,23 @@ def test_mask_bias_views_with_odd_key_tails(pkg, dev, S):
             _check(got, want, dtype, f"S={S} {nm}")
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("L", [2048, 2000])
+def test_head_dim_128_large_grid_sampled_rows(pkg, dev, L, causal):
+    """(2,32,L,128): enough 256-row blocks that the D=128 forward takes its 8-waves-per-workgroup kernel (full and ragged last
+    block, key count not a tile multiple); sampled rows of three heads against the oracle"""
+    from oracle.ref_attention import ref_attention_n_rows
+    dtype = torch.bfloat16
+    B, H, D, S = 2, 32, 128, L + 48
+    q, k, v = (_rand(sh, dtype, dev, s) for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1, is_causal=causal)
+    rows = torch.tensor([0, 1, 31, 32, 255, 256, 257, 1000, L - 1])
+    for b, h in ((0, 0), (1, 31), (0, 17)):
+        want = ref_attention_n_rows(q[b, h][rows.to(dev)].float().cpu(), rows, k[b, h].float().cpu(), v[b, h].float().cpu(), L,
+                                    softmax_n_param=1.0, is_causal=causal)
+        _check(out[b, h][rows.to(dev)], want, dtype, f"head ({b},{h})")
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 3, 8), (1, 2, 1, 64), (1, 1, 65, 16), (3, 2, 127, 96), (1, 1, 257, 40)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_ragged_and_padded_feature_dims(pkg, dev, shape, causal):
