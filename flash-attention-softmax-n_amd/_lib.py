@@ -16,7 +16,8 @@ FASN_BIAS_NONE, FASN_BIAS_SAME, FASN_BIAS_F32 = 0, 1, 2
 
 # every entry point include/fasn.h declares (tests check the .so exports all of them)
 EXPORTS = (
-    "fasn_abi_version", "fasn_strerror", "fasn_supported", "fasn_fwd", "fasn_bwd_workspace_bytes", "fasn_bwd",
+    "fasn_abi_version", "fasn_strerror", "fasn_supported", "fasn_fwd", "fasn_fwd_workspace_bytes", "fasn_fwd_ws",
+    "fasn_bwd_workspace_bytes", "fasn_bwd",
     "fasn_softmax_n_fwd", "fasn_softmax_n_bwd", "fasn_time_fwd", "fasn_time_bwd",
 )
 
@@ -72,6 +73,10 @@ def load():
     lib.fasn_supported.argtypes = [c_int32, c_int32, c_int32]
     lib.fasn_fwd.restype = c_int32
     lib.fasn_fwd.argtypes = [POINTER(FwdArgs), c_void_p]
+    lib.fasn_fwd_workspace_bytes.restype = c_size_t
+    lib.fasn_fwd_workspace_bytes.argtypes = [POINTER(FwdArgs)]
+    lib.fasn_fwd_ws.restype = c_int32
+    lib.fasn_fwd_ws.argtypes = [POINTER(FwdArgs), c_void_p, c_size_t, c_void_p]
     lib.fasn_bwd.restype = c_int32
     lib.fasn_bwd.argtypes = [POINTER(BwdArgs), c_void_p]
     lib.fasn_bwd_workspace_bytes.restype = c_size_t

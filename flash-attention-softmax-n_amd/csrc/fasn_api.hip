@@ -135,7 +135,35 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
         l.mode = a->causal ? MODE_CAUSAL : MODE_PLAIN;
     }
     l.variant = internal_variant();
+    p.nsplit = 1;
+    p.tps = 0;
+    p.part_o = nullptr;
+    p.part_ml = nullptr;
     return FASN_OK;
+}
+
+// Split-K plan for short-query / long-key shapes: too few (b,h, query block) workgroups to fill 256 CUs while each one
+// would walk many key tiles. Returns the number of key splits (1 = do not split) and the tiles per split (even).
+int plan_splitk(const fasn_fwd_args* a, const FwdParams& p, const FwdLaunch& l, int& tps) {
+    tps = 0;
+    if (l.dtype == FASN_DTYPE_F32 || p.drop_thr || l.mode == MODE_GENERAL_SLOW) return 1;
+    const int64_t base_blocks = (int64_t)a->B * a->H * ((a->Sq + 127) / 128);
+    int ntiles = (a->Sk + KT - 1) / KT;
+    if (a->causal) {   // the last row's visible keys bound the walk
+        const int kmax = a->Sk - 1;
+        ntiles = kmax / KT + 1;
+    }
+    if (base_blocks >= 256 || ntiles < 16) return 1;
+    int nsplit = (int)((1024 + base_blocks - 1) / base_blocks);
+    if (nsplit > ntiles / 4) nsplit = ntiles / 4;
+    if (nsplit < 2) return 1;
+    tps = (ntiles + nsplit - 1) / nsplit;
+    tps += tps & 1;
+    nsplit = (ntiles + tps - 1) / tps;
+    return nsplit < 2 ? 1 : nsplit;
+}
+size_t splitk_bytes(const fasn_fwd_args* a, int nsplit) {
+    return (size_t)a->B * a->H * nsplit * a->Sq * (size_t)(a->D + 2) * sizeof(float);
 }
 
 int dispatch_fwd(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
@@ -180,6 +208,33 @@ int fasn_fwd(const fasn_fwd_args* args, fasn_stream_t stream) {
     FwdLaunch l;
     const int rc = build_fwd(args, p, l);
     if (rc) return rc;
+    return dispatch_fwd(p, l, (hipStream_t)stream);
+}
+
+size_t fasn_fwd_workspace_bytes(const fasn_fwd_args* args) {
+    FwdParams p;
+    FwdLaunch l;
+    if (build_fwd(args, p, l)) return 0;
+    int tps;
+    const int nsplit = plan_splitk(args, p, l, tps);
+    return nsplit > 1 ? splitk_bytes(args, nsplit) : 0;
+}
+
+int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_bytes, fasn_stream_t stream) {
+    FwdParams p;
+    FwdLaunch l;
+    const int rc = build_fwd(args, p, l);
+    if (rc) return rc;
+    int tps;
+    const int nsplit = plan_splitk(args, p, l, tps);
+    if (nsplit > 1 && workspace != nullptr && workspace_bytes >= splitk_bytes(args, nsplit)) {
+        if (reinterpret_cast<uintptr_t>(workspace) % 16) return FASN_EALIGN;
+        p.nsplit = nsplit;
+        p.tps = tps;
+        p.part_o = static_cast<float*>(workspace);
+        p.part_ml = p.part_o + (size_t)args->B * args->H * nsplit * args->Sq * args->D;
+        return launch_fwd_splitk(p, l, (hipStream_t)stream);
+    }
     return dispatch_fwd(p, l, (hipStream_t)stream);
 }
 

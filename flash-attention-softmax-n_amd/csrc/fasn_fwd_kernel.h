@@ -55,6 +55,12 @@ struct FwdParams {
     float drop_scale;         // 256 / (256 - drop_thr): applied to O (and to dP in the backward)
     float c;        // scale * log2(e)
     float n;        // softmax_n
+    // split-K (SPLIT kernels, short query / long key "decode" shapes): the keys of one (b,h, query block) are divided over
+    // nsplit workgroups of tps tiles each; every workgroup writes its un-normalised fp32 accumulator and (m, l) per row,
+    // fasn_fwd_combine_kernel merges them. The sink (+n) belongs to split 0.
+    int nsplit, tps;
+    float* part_o;   // [B*H][nsplit][Sq][D]
+    float* part_ml;  // [B*H][nsplit][Sq][2]
 };
 
 constexpr int KT = 64;  // keys per tile
@@ -71,8 +77,9 @@ constexpr float kSumLimit = 256.0f;
 // RING: 2 = no staging registers at all: `buffer_load_dwordx4 ... lds` moves each 16-byte chunk straight from HBM/L2 into
 // the LDS tile image (LDS address = wave base + 16*lane, so the swizzle is applied by choosing WHICH global chunk a lane
 // fetches), three LDS tile buffers, loads issued two tiles ahead, `s_waitcnt vmcnt` before the barrier that publishes a tile.
-template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0, int RING = 0>
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0, int RING = 0, int SPLIT = 0>
 __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
+    static_assert(!SPLIT || (RING == 0 && DROP == 0 && ABL == 0), "split-K uses the plain staging scheme");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     constexpr int NT = NW * 64;
@@ -96,14 +103,19 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int l31 = lane & 31;
     const int hi = lane >> 5;
 
-    int bh, qi;
+    int bh, qi, split = 0;
     constexpr bool VEC = MODE == MODE_GENERAL || MODE == MODE_GENERAL_B || MODE == MODE_GENERAL_M;
     constexpr bool SLOW = MODE == MODE_GENERAL_SLOW;
     constexpr bool GEN = VEC || SLOW;
     constexpr bool VBIAS = MODE == MODE_GENERAL || MODE == MODE_GENERAL_B;   // vector bias present (compile time)
     constexpr bool VMASK = MODE == MODE_GENERAL || MODE == MODE_GENERAL_M;   // vector mask present (compile time)
     constexpr bool KPERM = VEC;
-    if (GEN && p.batch_inner && (p.H & 7) == 0) {
+    if (SPLIT) {
+        int blk;
+        block_to_work(blockIdx.x, p.B * p.H, p.nqblk * p.nsplit, bh, blk);
+        qi = blk / p.nsplit;
+        split = blk % p.nsplit;
+    } else if (GEN && p.batch_inner && (p.H & 7) == 0) {
         // per XCD: (head, q-block, batch) with the batch fastest -> the B workgroups that read the same bias tile run together
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         const int bb = j % p.B, rest = j / p.B;
@@ -133,6 +145,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         const int nt_c = kmax < 0 ? 0 : (kmax / KT + 1);
         ntiles = min(ntiles, nt_c);
     }
+    const int t_begin = SPLIT ? split * p.tps : 0;   // tps is even: tile parity = LDS buffer parity
+    if (SPLIT) ntiles = min(ntiles, t_begin + p.tps);
 
     // ---- Q fragments (B operand: col = q = lane&31, k = 8*hi..8*hi+7 of each 16-wide step)
     vec8 qf[QB][KS];
@@ -205,7 +219,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     f32x16 oacc[QB][DB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const bool sink = p.n > 0.f;
+        const bool sink = p.n > 0.f && split == 0;
         m_run[qb] = sink ? 0.f : -INFINITY;
         l_run[qb] = (sink && hi == 0) ? p.n : 0.f;  // the two half-lanes' partial sums are added at the end
 #pragma unroll
@@ -290,11 +304,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             stage_direct(1, 1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile 0 (and Q) landed; tile 1 in flight
         }
-    } else if (ntiles > 0) {
-        stage_load(0, Set0{});
+    } else if (ntiles > t_begin) {
+        stage_load(t_begin, Set0{});
         stage_store(0, Set0{});
         if (RING) stage_load(1, Set1{});   // tile 1 in flight in the second set
-        if (VEC) gen_dma(0);
+        if (VEC) gen_dma(t_begin);
     }
     __syncthreads();
 #pragma unroll
@@ -603,9 +617,34 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             if (t + 1 < ntiles) tile_body(t + 1, Set1{}, Set0{});
         }
     } else {
-        for (int t = 0; t < ntiles; ++t) tile_body(t, Set0{}, Set0{});
+        for (int t = t_begin; t < ntiles; ++t) tile_body(t, Set0{}, Set0{});
     }
 
+    if (SPLIT) {   // ---- partial result of this key range: un-normalised accumulator + (m, l) per row
+        float* po = p.part_o + ((int64_t)bh * p.nsplit + split) * p.Sq * D;
+        float* pml = p.part_ml + ((int64_t)bh * p.nsplit + split) * p.Sq * 2;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int row = qw0 + qb * 32 + l31;
+            const float l_tot = sum_across_halves(l_run[qb]);
+            if (row < p.Sq) {
+                if (hi == 0) {
+                    pml[row * 2] = m_run[qb];
+                    pml[row * 2 + 1] = l_tot;
+                }
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 x;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = oacc[qb][d][4 * g + e];
+                        *reinterpret_cast<f32x4*>(po + (int64_t)row * D + d * 32 + 8 * g + 4 * hi) = x;
+                    }
+            }
+        }
+        return;
+    }
     // ---- epilogue: O = acc / l, LSE = ln2 * (m + log2 l)
     char* obase = p.o + (b * p.os[0] + h * p.os[1]) * 2;
 #pragma unroll
@@ -633,6 +672,39 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 }
         }
     }
+}
+
+// Merge the split-K partials: m* = max_s m_s, l = sum_s l_s 2^(m_s - m*), O = sum_s acc_s 2^(m_s - m*) / l.
+// One thread per (row, 4 features).
+template <typename Tag, int D>
+__global__ void __launch_bounds__(256) fasn_fwd_combine_kernel(const FwdParams p) {
+    using E = ET<Tag>;
+    constexpr int TPR = D / 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t rowg = gid / TPR;   // (bh, row)
+    const int c4 = (int)(gid % TPR) * 4;
+    if (rowg >= (int64_t)p.B * p.H * p.Sq) return;
+    const int bh = (int)(rowg / p.Sq), row = (int)(rowg % p.Sq);
+    const int b = bh / p.H, h = bh % p.H;
+    float mstar = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s) mstar = fmaxf(mstar, p.part_ml[(((int64_t)bh * p.nsplit + s) * p.Sq + row) * 2]);
+    const float m_use = (mstar == -INFINITY) ? 0.f : mstar;
+    float l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.nsplit; ++s) {
+        const int64_t base = ((int64_t)bh * p.nsplit + s) * p.Sq + row;
+        const float ms = p.part_ml[base * 2], ls = p.part_ml[base * 2 + 1];
+        const float w = (ms == -INFINITY) ? 0.f : fast_exp2(ms - m_use);
+        l += ls * w;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.part_o + base * D + c4);
+        acc += a * w;
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    typename E::vec4 y = E::cvt4(acc * inv);
+    u32x2 raw;
+    __builtin_memcpy(&raw, &y, 8);
+    gstore8(p.o + (b * p.os[0] + h * p.os[1] + (int64_t)row * p.os[2] + c4) * 2, raw);
+    if (p.lse != nullptr && c4 == 0) p.lse[(int64_t)bh * p.Sq + row] = l > 0.f ? (m_use + __builtin_log2f(l)) * kLn2 : -INFINITY;
 }
 
 }  // namespace fasn

@@ -19,6 +19,7 @@ struct FwdLaunch {
 int launch_fwd_d32(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_fwd_d64(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_fwd_d128(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
+int launch_fwd_splitk(const FwdParams& p, const FwdLaunch& l, hipStream_t s);   // p.nsplit > 1, partial buffers set
 
 
 template <typename K>

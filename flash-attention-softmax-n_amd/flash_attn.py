@@ -86,7 +86,12 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         a = FwdArgs()
         _fill_fwd(a, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p, seed, 0)
         with torch.cuda.device(q.device):
-            _lib.check(lib.fasn_fwd(a, _stream_ptr(q.device)), "fasn_fwd")
+            ws_bytes = lib.fasn_fwd_workspace_bytes(a)   # > 0: short-query / long-key shape, keys split over workgroups
+            if ws_bytes:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+                _lib.check(lib.fasn_fwd_ws(a, ws.data_ptr(), ws_bytes, _stream_ptr(q.device)), "fasn_fwd_ws")
+            else:
+                _lib.check(lib.fasn_fwd(a, _stream_ptr(q.device)), "fasn_fwd")
         ctx.save_for_backward(q, k, v, o, lse, mask, bias)
         ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, ctx.seed = n, scale, causal, dropout_p, seed
         return o

@@ -113,6 +113,16 @@ int fasn_supported(int32_t dtype, int32_t D, int32_t Dv);
 
 int fasn_fwd(const fasn_fwd_args* args, fasn_stream_t stream);
 
+/*
+ * Forward with a caller-provided workspace: short-query / long-key ("decode") shapes have too few (batch, head, query block)
+ * units to fill the GPU, so the keys of each unit are split over several workgroups whose partial results
+ * (fp32 accumulator + running max / sum per row) are merged by a second kernel. fasn_fwd_workspace_bytes() returns the
+ * bytes that plan needs for `args` (0 = the plain path is used; fasn_fwd_ws then equals fasn_fwd). The workspace must be
+ * 16-byte aligned device memory; a NULL or too small workspace silently selects the plain path. Same results either way.
+ */
+size_t fasn_fwd_workspace_bytes(const fasn_fwd_args* args);
+int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_bytes, fasn_stream_t stream);
+
 size_t fasn_bwd_workspace_bytes(const fasn_bwd_args* args);
 int fasn_bwd(const fasn_bwd_args* args, fasn_stream_t stream);
 

@@ -214,6 +214,38 @@ def test_mask_bias_views_with_odd_key_tails(pkg, dev, S):
             _check(got, want, dtype, f"S={S} {nm}")
 
 
+@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("L,S", [(1, 4096), (5, 5000), (64, 2048), (130, 4100)])
+@pytest.mark.parametrize("kind", ["plain", "causal", "bias+mask"])
+def test_decode_shapes_take_the_split_key_path(pkg, dev, kind, L, S, D):
+    """few query rows, many keys: the keys of one (b,h) are split over workgroups and merged by the
+    combine kernel; same answers as the oracle, sink (+n) counted once, backward unchanged"""
+    from flash_attention_softmax_n_amd import _lib as L_
+    from flash_attention_softmax_n_amd.flash_attn import _fill_fwd
+    dtype = torch.bfloat16
+    B, H = 2, 3
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    mask = bias = None
+    if kind == "bias+mask":
+        gen = torch.Generator().manual_seed(3)
+        mask = synth.keypad_mask(B, S, device=dev)
+        bias = torch.randn(1, H, L, S, generator=gen).to(dtype).to(dev)
+    # the plan really is split-K for these shapes
+    a = L_.FwdArgs()
+    o_ = torch.empty_like(q)
+    lse_ = torch.empty((B, H, L), dtype=torch.float32, device=dev)
+    _fill_fwd(a, q.detach(), k.detach(), v.detach(), o_, lse_, None if mask is None else mask.expand(B, H, L, S).view(torch.uint8),
+              None if bias is None else bias.expand(B, H, L, S), 0.5, D ** -0.5, kind == "causal")
+    assert L_.load().fasn_fwd_workspace_bytes(a) > 0
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, is_causal=kind == "causal", attn_mask=mask, attn_bias=bias)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=0.5, is_causal=kind == "causal", attn_mask=mask,
+                                    attn_bias=None if bias is None else bias.float())
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"{kind} L={L} S={S} D={D} {nm}")
+
+
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("L", [2048, 2000])
 def test_head_dim_128_large_grid_sampled_rows(pkg, dev, L, causal):
