@@ -2,10 +2,11 @@
 
 Public surface = flash_attention_softmax_n/__init__.py:3-9 of the reference:
     flash_attention_n, softmax_n, slow_attention_n, flash_attention_n_triton (+ TRITON_INSTALLED for source compat)
+    surgery.apply_attention_softmax_n / surgery.policy_registry  (flash_attention_softmax_n/surgery, composer-free)
 Every function runs on device tensors through libfasn.so; importing the package without the built
 library raises ImportError (no silent fallback).
 """
-from . import _lib, dropout
+from . import _lib, dropout, surgery
 from .flash_attn import flash_attention_n, flash_attention_n_triton, slow_attention_n
 from .softmax import softmax_n
 

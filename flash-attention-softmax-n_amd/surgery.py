@@ -1,0 +1,173 @@
+"""Model surgery: put softmax_n attention (the HIP kernel) into existing models.
+
+Mirrors the reference's surgery interface without its MosaicML-composer dependency:
+    policy_registry / PolicyRegistry.register   surgery/surgery_functions/utils.py:12-97   (same signature rules and errors)
+    apply_attention_softmax_n(model, n, opts)    surgery/attention_softmax_n.py:19-63       (module replacement by policy)
+A surgery function has the signature `(module: torch.nn.Module, module_index: int, softmax_n_param: float)` and returns the
+module to keep in the model (the same object, modified in place, or a new one) or None to leave it alone.
+
+Built-in policy: Hugging Face self-attention modules that dispatch through `transformers.AttentionInterface`
+(transformers >= 4.48; BERT / RoBERTa here). The reference re-implements `BertSelfAttention.forward` around its eager
+`softmax_n` (surgery_functions/_bert.py:24-121, pinned to transformers < 4.33); here the module keeps its own forward and its
+attention function becomes `flash_attention_n` — fused, no [B,H,L,S] score tensor. XLNet's relative attention
+(surgery_functions/_xlnet.py) is not covered.
+"""
+from __future__ import annotations
+
+import inspect
+import logging
+from typing import Callable, Dict, Optional, Sequence, Type, Union
+
+import torch
+from torch.nn import Module
+from torch.optim import Optimizer
+
+log = logging.getLogger(__name__)
+
+AttentionSoftmaxNReplacementFunction = Callable[[Module, int, float], Optional[Module]]
+HF_ATTENTION_NAME = "softmax_n_hip"   # key under which the attention function is registered with transformers
+
+__all__ = ["PolicyRegistry", "policy_registry", "apply_attention_softmax_n", "register_hf_attention", "HF_ATTENTION_NAME"]
+
+
+class PolicyRegistry(Dict[Type[Module], AttentionSoftmaxNReplacementFunction]):
+    """module class -> surgery function (reference surgery_functions/utils.py:12-93)."""
+
+    def register(self, *modules: Type[Module]):
+        if len(modules) == 0:
+            raise ValueError("Registry decoration without any module class inputs has no effect.")
+
+        def check_signature(func: Callable) -> None:
+            params = list(inspect.signature(func).parameters.items())
+            if len(params) != 3:
+                raise ValueError(f"a surgery function takes (module, module_index, softmax_n_param); {func} takes {len(params)} arguments")
+            (_, p_module), (_, p_index), (n_name, p_n) = params
+            # annotations may be strings under `from __future__ import annotations`
+            def is_(annotation, typ, name):
+                return annotation is typ or annotation == name or annotation == f"torch.nn.{name}" or annotation == f"nn.{name}"
+            if not is_(p_module.annotation, Module, "Module"):
+                raise TypeError(f'the first argument of surgery function {func} must be annotated "torch.nn.Module"')
+            if not is_(p_index.annotation, int, "int"):
+                raise TypeError(f'the second argument of surgery function {func} must be annotated "int"')
+            if not is_(p_n.annotation, float, "float"):
+                raise TypeError(f'the third argument of surgery function {func} must be annotated "float"')
+            if n_name != "softmax_n_param":
+                raise NameError(f'the third argument of surgery function {func} must be named "softmax_n_param"')
+
+        def wrapper(func: AttentionSoftmaxNReplacementFunction) -> AttentionSoftmaxNReplacementFunction:
+            check_signature(func)
+            for m in modules:
+                if not (isinstance(m, type) and issubclass(m, Module)):
+                    raise TypeError(f"{getattr(m, '__name__', m)} is not a subclass of torch.nn.Module")
+                if m in self:
+                    raise ValueError(f"a surgery function is already registered for {m.__name__}")
+                self[m] = func
+            return func
+
+        return wrapper
+
+
+policy_registry = PolicyRegistry()
+
+
+def _swap_optimizer_params(optimizers, old: Module, new: Module) -> None:
+    """keep optimizers that were built on `model.parameters()` pointing at the parameters of the replacement module"""
+    if optimizers is None:
+        return
+    if isinstance(optimizers, Optimizer):
+        optimizers = [optimizers]
+    old_params = list(old.parameters())
+    new_params = list(new.parameters())
+    if {id(p) for p in old_params} == {id(p) for p in new_params}:
+        return
+    for opt in optimizers:
+        for group in opt.param_groups:
+            kept = [p for p in group["params"] if all(p is not q for q in old_params)]
+            if len(kept) != len(group["params"]):     # this group held the old module's parameters
+                for p in old_params:
+                    opt.state.pop(p, None)
+                group["params"] = kept + [p for p in new_params if all(p is not q for q in kept)]
+                new_params = []
+
+
+def apply_attention_softmax_n(model: Module, softmax_n_param: float,
+                              optimizers: Optional[Union[Optimizer, Sequence[Optimizer]]] = None) -> int:
+    """Run every registered surgery function over the matching sub-modules of `model` (reference
+    surgery/attention_softmax_n.py:19-63). Returns the number of modules converted; logs a warning when it is 0."""
+    replaced = 0
+    index = 0
+    # parents first, children collected before any replacement so a replacement's own sub-modules are not revisited
+    for parent in list(model.modules()):
+        for name, child in list(parent.named_children()):
+            func = next((f for cls, f in policy_registry.items() if type(child) is cls), None)
+            if func is None:
+                func = next((f for cls, f in policy_registry.items() if isinstance(child, cls)), None)
+            if func is None:
+                continue
+            new = func(child, index, softmax_n_param=float(softmax_n_param))
+            index += 1
+            if new is None:
+                continue
+            if new is not child:
+                setattr(parent, name, new)
+                _swap_optimizer_params(optimizers, child, new)
+            replaced += 1
+    if replaced == 0:
+        supported = "".join(sorted("\n\t" + c.__module__ + "." + c.__name__ for c in policy_registry))
+        log.warning("AttentionSoftmaxN had no effect on the model! Supported module classes: %s", supported)
+    else:
+        log.info("%d instances of AttentionSoftmaxN added", replaced)
+    return replaced
+
+
+# ------------------------------------------------------------------------------------------- Hugging Face transformers
+def _hf_attention(module: Module, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                  attention_mask: Optional[torch.Tensor], scaling: Optional[float] = None, dropout: float = 0.0, **kwargs):
+    """`transformers` attention-interface function: [B,H,L,E] in, ([B,L,H,Ev], None) out. The additive float mask HF builds
+    ([B,1,L,S], finfo.min where hidden) is passed as `attn_bias` through its broadcast strides."""
+    from .flash_attn import flash_attention_n
+    n = float(getattr(module, "softmax_n_param", 0.0))
+    bias = mask = None
+    if attention_mask is not None:
+        if attention_mask.dtype == torch.bool:
+            mask = attention_mask
+        else:
+            bias = attention_mask[..., : key.shape[-2]]
+    out = flash_attention_n(query, key, value, softmax_n_param=n, scale=scaling, dropout_p=dropout if module.training else 0.0,
+                            attn_mask=mask, attn_bias=bias, is_causal=bool(kwargs.get("is_causal", False)) and query.shape[2] > 1)
+    return out.transpose(1, 2).contiguous(), None
+
+
+def register_hf_attention() -> bool:
+    """Register the attention function with transformers (once) and the built-in surgery policy for the self-attention
+    classes of the installed version. Returns False when transformers has no AttentionInterface."""
+    try:
+        from transformers import AttentionInterface
+    except Exception:   # transformers missing or too old
+        return False
+    if HF_ATTENTION_NAME not in AttentionInterface._global_mapping:
+        AttentionInterface.register(HF_ATTENTION_NAME, _hf_attention)
+    classes = []
+    for mod_name, cls_names in (("transformers.models.bert.modeling_bert", ("BertSelfAttention", "BertCrossAttention")),
+                                ("transformers.models.roberta.modeling_roberta", ("RobertaSelfAttention", "RobertaCrossAttention"))):
+        try:
+            mod = __import__(mod_name, fromlist=list(cls_names))
+        except Exception:
+            continue
+        classes += [getattr(mod, c) for c in cls_names if hasattr(mod, c)]
+    classes = [c for c in classes if c not in policy_registry]
+    if classes:
+        policy_registry.register(*classes)(hf_self_attention_surgery)
+    return True
+
+
+def hf_self_attention_surgery(module: Module, module_index: int, softmax_n_param: float) -> Optional[Module]:
+    """Built-in policy for HF self-attention modules: remember n on the module and route its attention call to the HIP
+    kernel (the module's projections, cache handling and output reshaping stay its own)."""
+    del module_index
+    config = getattr(module, "config", None)
+    if config is None or not hasattr(config, "_attn_implementation"):
+        return None
+    module.softmax_n_param = float(softmax_n_param)
+    config._attn_implementation = HF_ATTENTION_NAME   # the config object is shared by all layers of the model
+    return module

@@ -1,0 +1,69 @@
+"""Surgery on a real model (-m gpu): a small random-weight BERT whose self-attention is switched to the HIP softmax_n
+kernel, against the same weights with an eager softmax_n attention built from the oracle (the reference's
+tests/cpu/surgery/test_bert.py checks its own patched forward the same way)."""
+import pytest
+import torch
+
+from oracle.ref_attention import ref_softmax_n
+
+pytestmark = pytest.mark.gpu
+
+transformers = pytest.importorskip("transformers")
+
+
+def _oracle_attention(module, query, key, value, attention_mask, scaling=None, dropout=0.0, **kwargs):
+    """eager attention with the oracle's softmax_n, fp32 arithmetic"""
+    n = float(getattr(module, "softmax_n_param", 0.0))
+    scaling = query.size(-1) ** -0.5 if scaling is None else scaling
+    w = torch.matmul(query.float(), key.float().transpose(2, 3)) * scaling
+    if attention_mask is not None:
+        w = w + attention_mask.float()
+    w = ref_softmax_n(w, n=n)
+    out = torch.matmul(w, value.float()).to(query.dtype)
+    return out.transpose(1, 2).contiguous(), None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n", [0.0, 1.0, 2.5])
+def test_bert_with_softmax_n_attention(pkg, dev, n, dtype):
+    from transformers import AttentionInterface, BertConfig, BertModel
+    from flash_attention_softmax_n_amd import surgery
+    if not surgery.register_hf_attention():
+        pytest.skip("transformers without AttentionInterface")
+    if "oracle_softmax_n" not in AttentionInterface._global_mapping:
+        AttentionInterface.register("oracle_softmax_n", _oracle_attention)
+    torch.manual_seed(0)
+    cfg = BertConfig(vocab_size=100, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                     max_position_embeddings=160, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = BertModel(cfg, add_pooling_layer=False).to(dev).to(dtype).eval()
+    ids = torch.randint(0, 100, (3, 150), device=dev)
+    att = torch.ones(3, 150, dtype=torch.long, device=dev)
+    att[1, 100:] = 0          # padded sequences -> additive mask -> attn_bias path
+    att[2, 37:] = 0
+
+    # expected: same weights, eager softmax_n attention
+    for m in model.modules():
+        if type(m).__name__ == "BertSelfAttention":
+            m.softmax_n_param = n
+    model.config._attn_implementation = "oracle_softmax_n"
+    with torch.no_grad():
+        want = model(input_ids=ids, attention_mask=att).last_hidden_state.float()
+
+    count = surgery.apply_attention_softmax_n(model, softmax_n_param=n)
+    assert count == cfg.num_hidden_layers
+    assert model.config._attn_implementation == surgery.HF_ATTENTION_NAME
+    with torch.no_grad():
+        got = model(input_ids=ids, attention_mask=att).last_hidden_state.float()
+    assert torch.isfinite(got).all()
+    valid = att.bool().unsqueeze(-1)
+    err = ((got - want) * valid).abs().max().item()
+    # two encoder layers in a 16-bit model: allow two units in the last place of the largest activation
+    ulp = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * want.abs().max().item()
+    assert err <= 2 * ulp, f"max-abs {err:.3e} over the un-padded positions (2 ulp = {2 * ulp:.3e})"
+
+    # gradients flow through the kernel's backward into the projection weights
+    model.train()
+    out = model(input_ids=ids, attention_mask=att).last_hidden_state
+    (out.float() * valid).pow(2).sum().backward()   # sum, not mean: fp16 gradients of a mean underflow
+    g = model.encoder.layer[0].attention.self.query.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0

@@ -1,0 +1,147 @@
+"""Host logic of the surgery interface (no GPU): registry rules (reference surgery_functions/utils.py:62-93), module
+replacement and optimizer bookkeeping (reference attention_softmax_n.py:19-63, tests/cpu/surgery/test_register.py)."""
+import logging
+from types import MethodType
+
+import pytest
+import torch
+from torch import Tensor
+from torch.nn import Linear, Module
+
+from oracle.ref_attention import analytic_answer, ref_attention_n
+
+import flash_attention_softmax_n_amd.surgery as surgery
+from flash_attention_softmax_n_amd.surgery import PolicyRegistry, apply_attention_softmax_n, policy_registry
+
+SCALE, FACTOR = 0.2, 2.0
+
+
+class DoubleAttention(Module):
+    """2 x softmax_0 attention (the reference test's dummy module, tests/cpu/surgery/test_register.py:26-35)"""
+
+    def __init__(self):
+        super().__init__()
+        self.factor = FACTOR
+
+    def forward(self, q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+        return self.factor * ref_attention_n(q, k, v, softmax_n_param=0.0, scale=SCALE)
+
+
+class DummyModel(Module):
+    def __init__(self):
+        super().__init__()
+        self.attn = DoubleAttention()
+        self.other = Linear(4, 4)
+
+    def forward(self, q, k, v):
+        return self.attn(q, k, v)
+
+
+def _new_forward(self, q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+    return self.factor * ref_attention_n(q, k, v, softmax_n_param=self.n, scale=SCALE)
+
+
+@pytest.fixture
+def clean_registry():
+    saved = dict(policy_registry)
+    yield policy_registry
+    policy_registry.clear()
+    policy_registry.update(saved)
+
+
+@pytest.mark.parametrize("weight", [10, 1, 0.1, -0.1, -1, -10])
+def test_register_and_apply(clean_registry, weight):
+    seen = []
+
+    @policy_registry.register(DoubleAttention)
+    def converter(module: Module, module_index: int, softmax_n_param: float) -> Module:
+        seen.append(module_index)
+        module.n = softmax_n_param
+        setattr(module, "forward", MethodType(_new_forward, module))
+        return module
+
+    N, L, S, E = 2, 3, 5, 8
+    model = DummyModel()
+    q, k, v = (weight * torch.ones(N, sz, E) for sz in (L, S, S))
+    before = model(q, k, v)
+    assert torch.allclose(before, torch.full_like(before, FACTOR * analytic_answer(weight, S, E, SCALE, 0.0)), atol=1e-5)
+    assert apply_attention_softmax_n(model, softmax_n_param=2.0) == 1
+    assert seen == [0] and model.attn.n == 2.0
+    after = model(q, k, v)
+    assert torch.allclose(after, torch.full_like(after, FACTOR * analytic_answer(weight, S, E, SCALE, 2.0)), atol=1e-5)
+
+
+def test_registry_rejects_bad_surgery_functions():
+    reg = PolicyRegistry()
+    with pytest.raises(ValueError):
+        reg.register()
+    with pytest.raises(ValueError):
+        reg.register(DoubleAttention)(lambda module, module_index: module)
+
+    def bad_first(module: int, module_index: int, softmax_n_param: float):
+        return None
+
+    def bad_second(module: Module, module_index: float, softmax_n_param: float):
+        return None
+
+    def bad_third(module: Module, module_index: int, softmax_n_param: int):
+        return None
+
+    def bad_name(module: Module, module_index: int, n: float):
+        return None
+
+    def good(module: Module, module_index: int, softmax_n_param: float):
+        return None
+
+    for f, err in ((bad_first, TypeError), (bad_second, TypeError), (bad_third, TypeError), (bad_name, NameError)):
+        with pytest.raises(err):
+            reg.register(DoubleAttention)(f)
+    with pytest.raises(TypeError):
+        reg.register(int)(good)
+    reg.register(DoubleAttention)(good)
+    with pytest.raises(ValueError):
+        reg.register(DoubleAttention)(good)
+    assert reg[DoubleAttention] is good
+
+
+def test_no_match_warns_and_none_result_keeps_module(clean_registry, caplog):
+    policy_registry.clear()
+    model = DummyModel()
+    with caplog.at_level(logging.WARNING, logger=surgery.__name__):
+        assert apply_attention_softmax_n(model, 1.0) == 0
+    assert "had no effect" in caplog.text
+
+    @policy_registry.register(DoubleAttention)
+    def declines(module: Module, module_index: int, softmax_n_param: float):
+        return None
+
+    old = model.attn
+    assert apply_attention_softmax_n(model, 1.0) == 0 and model.attn is old
+
+
+def test_replacement_module_and_optimizer_params(clean_registry):
+    @policy_registry.register(Linear)
+    def widen(module: Module, module_index: int, softmax_n_param: float) -> Module:
+        return Linear(module.in_features, module.out_features, bias=False)
+
+    model = DummyModel()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    old_params = list(model.other.parameters())
+    assert apply_attention_softmax_n(model, 1.0, optimizers=opt) == 1
+    new_params = list(model.other.parameters())
+    assert len(new_params) == 1 and model.other.bias is None
+    in_opt = [p for g in opt.param_groups for p in g["params"]]
+    assert all(any(p is q for q in in_opt) for p in new_params)
+    assert not any(any(p is q for q in in_opt) for p in old_params)
+
+
+def test_hf_policy_registration_is_idempotent(clean_registry):
+    pytest.importorskip("transformers")
+    if not surgery.register_hf_attention():
+        pytest.skip("transformers without AttentionInterface")
+    n1 = len(policy_registry)
+    assert surgery.register_hf_attention() and len(policy_registry) == n1
+    from transformers import AttentionInterface
+    from transformers.models.bert.modeling_bert import BertSelfAttention
+    assert surgery.HF_ATTENTION_NAME in AttentionInterface._global_mapping
+    assert policy_registry[BertSelfAttention] is surgery.hf_self_attention_surgery
