@@ -21,6 +21,9 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.variant == 13) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 0>(p, l.mode, s);   // 8 waves share one K/V tile
     if (l.variant == 14) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 2>(p, l.mode, s);   // + direct-to-LDS staging
     if (l.variant == 15) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 1>(p, l.mode, s);
+    if (l.variant == 16) return launch_fwd_cfg<Tag, 128, 2, 1, 4, 1>(p, l.mode, s);   // 64 rows per wave, one wave per SIMD
+    if (l.variant == 17) return launch_fwd_cfg<Tag, 128, 2, 1, 4, 0>(p, l.mode, s);
+    if (l.variant == 18) return launch_fwd_cfg<Tag, 128, 2, 1, 4, 2>(p, l.mode, s);
     if (l.variant == 21) return launch_fwd_abl<Tag, 128, 1, 2, 1>(p, s);
     if (l.variant == 23) return launch_fwd_abl<Tag, 128, 1, 2, 3>(p, s);
     if (l.variant == 25) return launch_fwd_abl<Tag, 128, 1, 2, 5>(p, s);
