@@ -12,8 +12,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-template <int LDS>
+template <int LDS, int PRIO = 0>
 __global__ void __launch_bounds__(512) kern(float* out, int iters) {
+    if (PRIO && (threadIdx.x >> 8)) __builtin_amdgcn_s_setprio(PRIO);   // waves 4-7 (second wave of each SIMD)
     __shared__ __attribute__((aligned(16))) char lds[32768];
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 8192; i += blockDim.x) ((unsigned*)lds)[i] = 0x3c003c00u + i;
@@ -68,16 +69,16 @@ __global__ void __launch_bounds__(512) kern(float* out, int iters) {
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
-template <int LDS>
+template <int LDS, int PRIO = 0>
 static float run(int nwaves, int blocks_per_cu, int iters) {
     float* d;
     CHECK(hipMalloc(&d, 256 * 8 * 512 * 4));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(kern<LDS>, dim3(256 * blocks_per_cu), dim3(nwaves * 64), 0, 0, d, 10);
+    hipLaunchKernelGGL((kern<LDS, PRIO>), dim3(256 * blocks_per_cu), dim3(nwaves * 64), 0, 0, d, 10);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(kern<LDS>, dim3(256 * blocks_per_cu), dim3(nwaves * 64), 0, 0, d, iters);
+    hipLaunchKernelGGL((kern<LDS, PRIO>), dim3(256 * blocks_per_cu), dim3(nwaves * 64), 0, 0, d, iters);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -95,5 +96,11 @@ int main() {
     }
     float a = run<0>(8, 1, it), b = run<1>(8, 1, it);
     printf("2 waves/SIMD as one 8-wave block: regs-only %.1f ns   with LDS %.1f ns\n", a * 1e6 / it / 2, b * 1e6 / it / 2);
+    for (int pr = 1; pr <= 3; pr += 2) {
+        float c = pr == 1 ? run<0, 1>(8, 1, it) : run<0, 3>(8, 1, it), d = pr == 1 ? run<1, 1>(8, 1, it) : run<1, 3>(8, 1, it);
+        printf("  same, waves 4-7 at s_setprio %d: regs-only %.1f ns   with LDS %.1f ns\n", pr, c * 1e6 / it / 2, d * 1e6 / it / 2);
+    }
+    float e = run<0, 3>(16, 1, it);
+    printf("4 waves/SIMD as one 16-wave block, waves 4-15 at prio 3: regs-only %.1f ns\n", e * 1e6 / it / 4);
     return 0;
 }

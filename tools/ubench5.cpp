@@ -77,6 +77,37 @@ __global__ void __launch_bounds__(256, 2) kern(float* out, int iters) {
                 else { v_out(g - 1); v_out(g); v_fma(g + 1); v_fma(g + 2); }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else if (ORDER == 3) {   // deeper skew: exponential two groups after its fma, consumers two groups after the exponential
+            f32x2 tq4[4], xq4[4];
+            auto fma4 = [&](int i) { if (i < 0 || i > 15) return; const f32x16& src = DEP ? sacc[C][i >> 3] : cst[i >> 3];
+                const f32x2 s2 = {src[2 * (i & 7)], src[2 * (i & 7) + 1]}; tq4[i & 3] = __builtin_elementwise_fma(s2, c2, m2); };
+            auto exp4 = [&](int i) { if (i < 0 || i > 15) return; xq4[i & 3] = f32x2{__builtin_amdgcn_exp2f(tq4[i & 3][0]), __builtin_amdgcn_exp2f(tq4[i & 3][1])}; };
+            auto out4 = [&](int i) { if (i < 0 || i > 15) return; rs2 += xq4[i & 3]; const bf16x2 h2 = __builtin_convertvector(xq4[i & 3], bf16x2);
+                const int kb = i >> 3, t2 = (i >> 2) & 1, e = 2 * (i & 3); pf[C][kb][t2][e] = h2[0]; pf[C][kb][t2][e + 1] = h2[1]; };
+#pragma unroll
+            for (int i = -4; i < 0; ++i) { out4(i); exp4(i + 2); fma4(i + 4); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { mm(i); out4(i); exp4(i + 2); fma4(i + 4); __builtin_amdgcn_sched_barrier(0); }
+        } else if (ORDER == 4) {   // VALU first, MFMA last in each group
+#pragma unroll
+            for (int i = -LEAD; i < 0; ++i) { v_out(i + LEAD - 2); v_exp(i + LEAD - 1); v_fma(i + LEAD); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { v_out(i + LEAD - 2); v_exp(i + LEAD - 1); v_fma(i + LEAD); mm(i); __builtin_amdgcn_sched_barrier(0); }
+        } else if (ORDER == 5) {   // no pinning at all: the compiler's own order
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mm(i);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { v_fma(i); v_exp(i); v_out(i); }
+        } else if (ORDER == 6) {   // two MFMAs, then the arithmetic of two pairs
+            v_fma(0); v_fma(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 16; g += 2) {
+                mm(g); mm(g + 1);
+                v_exp(g); v_exp(g + 1); v_out(g - 2); v_out(g - 1); v_fma(g + 2); v_fma(g + 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            v_out(14); v_out(15);
         } else if (ORDER == 2) {   // batched by four: groups 4k, 4k+1: 4 exps each; groups 4k+2, 4k+3: packed ops of 4 pairs
             // pairs 4k..4k+3 exponentiated in groups 4k (pairs 4k,4k+1) and 4k+1 (4k+2,4k+3); out in 4k+2 / 4k+3; fma for the next four in 4k+2 / 4k+3
         }
@@ -98,7 +129,7 @@ static void run(const char* what, int it) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     printf("%-58s", what);
-    for (int w : {1, 2}) {
+    for (int w : {1, 2, 3}) {
         hipLaunchKernelGGL((kern<FLAGS, ORDER>), dim3(256 * w), dim3(256), 0, 0, d, 10);
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0, 0));
@@ -106,7 +137,7 @@ static void run(const char* what, int it) {
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-        printf("  %d wave/SIMD: %6.1f ns/wave-iter", w, ms * 1e6 / it / w);
+        printf("  %dw %6.1f", w, ms * 1e6 / it / w);
     }
     printf("\n");
     CHECK(hipFree(d));
@@ -118,6 +149,10 @@ int main() {
     run<16>("MFMA only", it);
     run<127>("everything (real dependencies)", it);
     run<127, 1>("everything, exponentials batched 4 per other group", it);
+    run<127, 3>("everything, deeper skew (2 groups per stage)", it);
+    run<127, 4>("everything, VALU first / MFMA last in a group", it);
+    run<127, 5>("everything, compiler's order (MFMA burst, then VALU)", it);
+    run<127, 6>("everything, groups of two MFMAs", it);
     run<16 + 1 + 32, 1>("MFMA + exp only, batched", it);
     run<127 - 64>("everything, PV operand loop-invariant", it);
     run<127 - 32>("everything, VALU input loop-invariant", it);
