@@ -24,6 +24,18 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.variant == 16) return launch_fwd_cfg<Tag, 128, 2, 1, 4, 1>(p, l.mode, s);   // 64 rows per wave, one wave per SIMD
     if (l.variant == 17) return launch_fwd_cfg<Tag, 128, 2, 1, 4, 0>(p, l.mode, s);
     if (l.variant == 18) return launch_fwd_cfg<Tag, 128, 2, 1, 4, 2>(p, l.mode, s);
+    if (l.variant == 4) return launch_fwd_pipe_mode<Tag, 128, 1, 2>(p, l.mode, s);      // software-pipelined, compiler order
+    if (l.variant == 5) return launch_fwd_pipe_mode<Tag, 128, 1, 2, 1>(p, l.mode, s);   // + burst order
+    if (l.variant == 6) return launch_fwd_pipe_mode<Tag, 128, 1, 1>(p, l.mode, s);
+    if (l.variant == 50) return launch_fwd_split<Tag, 128, 1, 2>(p, l.mode, s);   // 32-key sub-tiles
+    if (l.variant == 51) return launch_fwd_split<Tag, 128, 1, 1>(p, l.mode, s);
+    if (l.variant == 31) return launch_fwd_abl8<Tag, 128, 1, 2, 1>(p, s);   // 8-wave ablations: no exp
+    if (l.variant == 33) return launch_fwd_abl8<Tag, 128, 1, 2, 3>(p, s);   //   no PV MFMAs
+    if (l.variant == 35) return launch_fwd_abl8<Tag, 128, 1, 2, 5>(p, s);   //   no LDS fragment reads
+    if (l.variant == 36) return launch_fwd_abl8<Tag, 128, 1, 2, 6>(p, s);   //   no staging, no barrier
+    if (l.variant == 37) return launch_fwd_abl8<Tag, 128, 1, 2, 7>(p, s);   //   5 + 6
+    if (l.variant == 38) return launch_fwd_abl8<Tag, 128, 1, 2, 8>(p, s);   //   barrier, no staging
+    if (l.variant == 39) return launch_fwd_abl8<Tag, 128, 1, 2, 9>(p, s);   //   staging, no barrier
     if (l.variant == 21) return launch_fwd_abl<Tag, 128, 1, 2, 1>(p, s);
     if (l.variant == 23) return launch_fwd_abl<Tag, 128, 1, 2, 3>(p, s);
     if (l.variant == 25) return launch_fwd_abl<Tag, 128, 1, 2, 5>(p, s);

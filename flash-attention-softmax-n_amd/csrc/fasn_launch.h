@@ -153,6 +153,18 @@ int launch_fwd_pp_mode(const FwdParams& p, int mode, hipStream_t s) {
     return launch_fwd_pp_one<Tag, D, MODE_CAUSAL, OCC>(p, s);
 }
 
+// developer ablation launcher for 8-wave workgroups (plain mode)
+template <typename Tag, int D, int QB, int OCC, int ABL>
+int launch_fwd_abl8(FwdParams p, hipStream_t s) {
+    constexpr int BM = 8 * QB * 32;
+    constexpr int smem = 4 * KT * D * 2;
+    p.nqblk = (p.Sq + BM - 1) / BM;
+    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_PLAIN, OCC, 8, 0, ABL>;
+    set_smem_attr(kern, smem);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(512), smem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
 // any (workgroup size, staging scheme) combination of the plain / causal kernel
 template <typename Tag, int D, int QB, int OCC, int NW, int RING>
 int launch_fwd_cfg(FwdParams p, int mode, hipStream_t s) {
