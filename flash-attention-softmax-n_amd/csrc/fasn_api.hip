@@ -155,10 +155,10 @@ int plan_splitk(const fasn_fwd_args* a, const FwdParams& p, const FwdLaunch& l, 
     }
     if (base_blocks >= 256 || ntiles < 16) return 1;
     int nsplit = (int)((1024 + base_blocks - 1) / base_blocks);
-    if (nsplit > ntiles / 4) nsplit = ntiles / 4;
+    if (nsplit > ntiles / 6) nsplit = ntiles / 6;
     if (nsplit < 2) return 1;
     tps = (ntiles + nsplit - 1) / nsplit;
-    tps += tps & 1;
+    tps = (tps + 5) / 6 * 6;   // multiple of 6: the LDS buffer rotation (2 or 3 buffers) starts at buffer 0 in every split
     nsplit = (ntiles + tps - 1) / tps;
     return nsplit < 2 ? 1 : nsplit;
 }

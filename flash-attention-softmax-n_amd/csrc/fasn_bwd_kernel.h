@@ -402,6 +402,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         __syncthreads();
     }
 
+    if (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the image requested for the tile past the end has landed
     char* dqbase = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1]) * 2;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {

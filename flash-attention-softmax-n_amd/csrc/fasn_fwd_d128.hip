@@ -45,7 +45,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     // K/V tile, tiles loaded two ahead in two register sets) beats two 4-wave workgroups: 1134 vs 1014 TFLOP/s at
     // (4,32,8192,128) bf16, 886 vs 790 at (2,16,2048,128); staging + barrier cost 26 % of the 4-wave kernel at D = 128
     const long blocks256 = (long)((p.Sq + 255) / 256) * p.B * p.H;
-    if (l.variant == 0 && blocks256 >= 512) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 1>(p, l.mode, s);
+    if (l.variant == 0 && blocks256 >= 512 && p.Sq >= 256) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 1>(p, l.mode, s);
     return launch_fwd_mode<Tag, 128, 1, 2>(p, l.mode, s);
 }
 int launch_fwd_d128(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {

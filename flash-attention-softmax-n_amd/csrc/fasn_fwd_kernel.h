@@ -79,7 +79,7 @@ constexpr float kSumLimit = 256.0f;
 // fetches), three LDS tile buffers, loads issued two tiles ahead, `s_waitcnt vmcnt` before the barrier that publishes a tile.
 template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0, int RING = 0, int SPLIT = 0>
 __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
-    static_assert(!SPLIT || (RING == 0 && DROP == 0 && ABL == 0), "split-K uses the plain staging scheme");
+    static_assert(!SPLIT || (RING != 1 && DROP == 0 && ABL == 0), "split-K: single-set or direct-to-LDS staging");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     constexpr int NT = NW * 64;
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         const int nt_c = kmax < 0 ? 0 : (kmax / KT + 1);
         ntiles = min(ntiles, nt_c);
     }
-    const int t_begin = SPLIT ? split * p.tps : 0;   // tps is even: tile parity = LDS buffer parity
+    const int t_begin = SPLIT ? split * p.tps : 0;   // tps is a multiple of 6: t & 1 and t % 3 select the LDS buffer as if t started at 0
     if (SPLIT) ntiles = min(ntiles, t_begin + p.tps);
 
     // ---- Q fragments (B operand: col = q = lane&31, k = 8*hi..8*hi+7 of each 16-wide step)
@@ -298,10 +298,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     constexpr bool bias_fold = VBIAS;
     const float binv = bias_fold ? kLog2e / p.c : 0.f;
     if (RING == 2) {
-        if (ntiles > 0) {
-            if (VEC) gen_dma(0);
-            stage_direct(0, 0);
-            stage_direct(1, 1);
+        if (ntiles > t_begin) {
+            if (VEC) gen_dma(t_begin);
+            stage_direct(t_begin, 0);
+            stage_direct(t_begin + 1, 1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile 0 (and Q) landed; tile 1 in flight
         }
     } else if (ntiles > t_begin) {
@@ -342,6 +342,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             need_mask = (k0 + KT - 1) > wave_first_vis;
         }
         if (k0 + KT > p.Sk) need_mask = true;
+        if (qw0 >= p.Sq) skip = true;   // short query blocks (decode shapes): a wave without rows only helps staging the tiles
 
         // VEC: mask bytes of this lane's elements, 4 consecutive keys per load; SLOW: every tile takes the exact path
         uint32_t mraw[QB][2][4];
@@ -619,6 +620,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     } else {
         for (int t = t_begin; t < ntiles; ++t) tile_body(t, Set0{}, Set0{});
     }
+    // direct-to-LDS requests issued for tiles past the end must land before this workgroup's LDS can be handed to another one
+    if (RING == 2 || VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (SPLIT) {   // ---- partial result of this key range: un-normalised accumulator + (m, l) per row
         float* po = p.part_o + ((int64_t)bh * p.nsplit + split) * p.Sq * D;

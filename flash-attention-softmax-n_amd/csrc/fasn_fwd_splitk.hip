@@ -7,10 +7,13 @@ namespace {
 template <typename Tag, int D, int MODE>
 int launch_splitk_one(FwdParams p, hipStream_t s) {
     constexpr int BM = 128;
-    constexpr int OCC = D == 128 ? 1 : 2;
-    constexpr int smem = 4 * KT * D * 2 + (MODE == MODE_GENERAL ? 4 * 6144 : 0);
+    // memory-bound: D <= 64: K/V go straight to LDS, two tiles ahead (three buffers of 8-16 KiB, three workgroups per CU);
+    // D = 128: register staging, two LDS buffers, so that two workgroups (2 x 64 KiB) fit on a CU
+    constexpr int RING = (D == 128 && MODE != MODE_GENERAL) ? 0 : 2;   // (the D = 128 mask/bias kernel spills with staging registers)
+    constexpr int OCC = 2;
+    constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2 + (MODE == MODE_GENERAL ? 4 * 6144 : 0);
     p.nqblk = (p.Sq + BM - 1) / BM;
-    auto kern = fasn_fwd_kernel<Tag, D, 1, MODE, OCC, 4, 0, 0, 0, 0, 1>;
+    auto kern = fasn_fwd_kernel<Tag, D, 1, MODE, OCC, 4, 0, 0, 0, RING, 1>;
     set_smem_attr(kern, smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.nsplit * p.B * p.H)), dim3(256), smem, s, p);
     const int64_t nthr = (int64_t)p.B * p.H * p.Sq * (D / 4);
