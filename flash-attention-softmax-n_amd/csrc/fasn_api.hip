@@ -43,8 +43,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     if (a->dtype != FASN_DTYPE_F16 && a->dtype != FASN_DTYPE_BF16 && a->dtype != FASN_DTYPE_F32) return FASN_EDTYPE;
     if (!fasn_supported(a->dtype, a->D, a->Dv)) return FASN_EHEADDIM;
     const int esize = a->dtype == FASN_DTYPE_F32 ? 4 : 2;
-    // the fp32 kernels cover plain and causal attention; masks, bias and dropout are features of the 16-bit paths
-    if (esize == 4 && (a->mask.ptr || a->bias.ptr || a->dropout_p != 0.f)) return FASN_EUNSUPPORTED;
+    // fp32 q/k/v: the bias, if any, must be fp32 as well (FASN_BIAS_SAME means fp32 then)
     if (!(a->dropout_p >= 0.f) || a->dropout_p >= 1.f) return FASN_EINVAL;
     if (!(a->softmax_n >= 0.f) || !(a->scale >= 0.f) || !isfinite(a->scale)) return FASN_EINVAL;
     int rc;
@@ -77,7 +76,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     p.Sk = a->Sk;
     p.nqblk = 0;
     p.causal = a->causal ? 1 : 0;
-    p.bias_f32 = (a->bias.ptr && a->bias_dtype == FASN_BIAS_F32) ? 1 : 0;
+    p.bias_f32 = (a->bias.ptr && (a->bias_dtype == FASN_BIAS_F32 || esize == 4)) ? 1 : 0;
     p.bias_vec = 0;
     p.mask_vec = 0;
     p.batch_inner = 0;

@@ -42,6 +42,14 @@ static int bwd_one(BwdParams p, hipStream_t s) {
 
 int launch_fwd_f32(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     const bool c = l.mode == MODE_CAUSAL;
+    if (l.mode >= MODE_GENERAL || p.drop_thr) {   // mask / bias / dropout: element-load instantiation
+        switch (l.D) {
+            case 32: return fwd_one<32, MODE_GENERAL_SLOW>(p, s);
+            case 64: return fwd_one<64, MODE_GENERAL_SLOW>(p, s);
+            case 128: return fwd_one<128, MODE_GENERAL_SLOW>(p, s);
+            default: return -3;
+        }
+    }
     switch (l.D) {
         case 32: return c ? fwd_one<32, MODE_CAUSAL>(p, s) : fwd_one<32, MODE_PLAIN>(p, s);
         case 64: return c ? fwd_one<64, MODE_CAUSAL>(p, s) : fwd_one<64, MODE_PLAIN>(p, s);
@@ -52,6 +60,14 @@ int launch_fwd_f32(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 
 int launch_bwd_f32(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
     const bool c = l.mode == MODE_CAUSAL;
+    if (l.mode >= MODE_GENERAL || p.f.drop_thr) {
+        switch (l.D) {
+            case 32: return bwd_one<32, MODE_GENERAL_SLOW>(p, s);
+            case 64: return bwd_one<64, MODE_GENERAL_SLOW>(p, s);
+            case 128: return bwd_one<128, MODE_GENERAL_SLOW>(p, s);
+            default: return -3;
+        }
+    }
     switch (l.D) {
         case 32: return c ? bwd_one<32, MODE_CAUSAL>(p, s) : bwd_one<32, MODE_PLAIN>(p, s);
         case 64: return c ? bwd_one<64, MODE_CAUSAL>(p, s) : bwd_one<64, MODE_PLAIN>(p, s);

@@ -62,6 +62,26 @@ struct Stage32 {
 // row of the accumulator register r for lane-half hi
 FASN_DEV int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// MODE_GENERAL_SLOW in the fp32 kernels = mask and/or bias and/or dropout, element loads through the four strides (the fp32
+// kernels run at the fp32 MFMA rate, 1/16 of bf16, so the loads are not what limits them). Bias elements are fp32 here.
+struct GenElem {
+    const float* bias;
+    const uint8_t* mask;
+    FASN_DEV void init(const FwdParams& p, int b, int h) {
+        bias = p.bias ? reinterpret_cast<const float*>(p.bias) + (b * p.bs[0] + h * p.bs[1]) : nullptr;
+        mask = p.mask ? p.mask + (b * p.ms[0] + h * p.ms[1]) : nullptr;
+    }
+    // y (log2 domain) += bias*log2e; returns false when the mask hides the element. (row, key) must be in range.
+    FASN_DEV bool apply(const FwdParams& p, int row, int key, float& y) const {
+        if (bias) y = __builtin_fmaf(bias[(int64_t)row * p.bs[2] + (int64_t)key * p.bs[3]], kLog2e, y);
+        return mask ? mask[(int64_t)row * p.ms[2] + (int64_t)key * p.ms[3]] != 0 : true;
+    }
+};
+FASN_DEV bool f32_keep(const FwdParams& p, int bh, int row, int key) {
+    const uint32_t hsh = drop_hash(drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row), p.seed_hi, (uint32_t)(key >> 2));
+    return drop_keep(hsh, key & 3, p.drop_thr);
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int D, int MODE>
 __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
@@ -74,10 +94,13 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bh, qi;
     block_to_work(blockIdx.x, p.B * p.H, p.nqblk, bh, qi);
-    constexpr bool causal = MODE == MODE_CAUSAL;
+    constexpr bool GEN = MODE == MODE_GENERAL_SLOW;
+    const bool causal = MODE == MODE_CAUSAL || (GEN && p.causal);
     const int qblk = causal ? (p.nqblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * BM, qw0 = q0 + wave * 32, row = qw0 + l31, coff = p.Sk - p.Sq;
+    GenElem ge;
+    if (GEN) ge.init(p, b, h);
     const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 4;
     const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 4;
     const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 4;
@@ -140,7 +163,10 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + kb * 32 + acc_row(r, hi);
-                const float y = (key < p.Sk && key <= vis) ? sacc[kb][r] * p.c : -INFINITY;
+                bool show = key < p.Sk && key <= vis;
+                float y = sacc[kb][r] * p.c;
+                if (GEN && show && row < p.Sq) show = ge.apply(p, row, key, y);
+                y = show ? y : -INFINITY;
                 sacc[kb][r] = y;
                 mx = fmaxf(mx, y);
             }
@@ -154,7 +180,8 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 sacc[kb][r] = fast_exp2(sacc[kb][r] - m_use);
-                rs += sacc[kb][r];
+                rs += sacc[kb][r];   // the row sum keeps the undropped weights
+                if (GEN && p.drop_thr && !f32_keep(p, bh, row, k0 + kb * 32 + acc_row(r, hi))) sacc[kb][r] = 0.f;
             }
         l_run = l_run * alpha + rs;
         m_run = m_new;
@@ -179,7 +206,7 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
         __syncthreads();
     }
     const float l_tot = sum_across_halves(l_run);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const float inv = l_tot > 0.f ? ((GEN && p.drop_thr) ? p.drop_scale : 1.0f) / l_tot : 0.f;
     if (row < p.Sq) {
         if (p.lse != nullptr && hi == 0) {
             const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
@@ -230,10 +257,13 @@ __global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bh, qi;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
-    constexpr bool causal = MODE == MODE_CAUSAL;
+    constexpr bool GEN = MODE == MODE_GENERAL_SLOW;
+    const bool causal = MODE == MODE_CAUSAL || (GEN && p.causal);
     const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * BM, qw0 = q0 + wave * 32, row = qw0 + l31, coff = p.Sk - p.Sq;
+    GenElem ge;
+    if (GEN) ge.init(p, b, h);
     const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 4;
     const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 4;
     int ntiles = (p.Sk + 63) / 64;
@@ -307,9 +337,14 @@ __global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + kb * 32 + acc_row(r, hi);
-                float pv = fast_exp2(__builtin_fmaf(sacc[kb][r], p.c, -lse2));
-                pv = (key < p.Sk && key <= vis) ? pv : 0.f;
-                sacc[kb][r] = pv * (pacc[kb][r] - dlt);   // dS^T (without the scale factor)
+                bool show = key < p.Sk && key <= vis;
+                float y = sacc[kb][r] * p.c;
+                if (GEN && show && ok) show = ge.apply(p, row, key, y);
+                float pv = fast_exp2(y - lse2);
+                pv = show ? pv : 0.f;
+                float dp = pacc[kb][r];
+                if (GEN && p.drop_thr) dp = f32_keep(p, bh, row, key) ? dp * p.drop_scale : 0.f;
+                sacc[kb][r] = pv * (dp - dlt);   // dS^T (without the scale factor)
             }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -353,9 +388,12 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bh, kblk;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
-    constexpr bool causal = MODE == MODE_CAUSAL;
+    constexpr bool GEN = MODE == MODE_GENERAL_SLOW;
+    const bool causal = MODE == MODE_CAUSAL || (GEN && p.causal);
     const int b = bh / p.H, h = bh % p.H;
     const int kw0 = kblk * BN + wave * 32, key = kw0 + l31, coff = p.Sk - p.Sq;
+    GenElem ge;
+    if (GEN) ge.init(p, b, h);
     const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 4;
     const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 4;
     const float* lsebase = p.lse + (int64_t)bh * p.Sq;
@@ -448,10 +486,19 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
             for (int r = 0; r < 16; ++r) {
                 const int rr = qb * 32 + acc_row(r, hi);
                 const int row = r0 + rr;
-                float pv = fast_exp2(__builtin_fmaf(sacc[r], p.c, -tL[rr]));
-                pv = (ok && row < p.Sq && (!causal || key <= row + coff)) ? pv : 0.f;
-                sacc[r] = pv;
-                pacc[r] = pv * (pacc[r] - tX[rr]);
+                bool show = ok && row < p.Sq && (!causal || key <= row + coff);
+                float y = sacc[r] * p.c;
+                if (GEN && show) show = ge.apply(p, row, key, y);
+                float pv = fast_exp2(y - tL[rr]);
+                pv = show ? pv : 0.f;
+                float dp = pacc[r], pd = pv;
+                if (GEN && p.drop_thr) {
+                    const bool keep = f32_keep(p, bh, row, key);
+                    dp = keep ? dp * p.drop_scale : 0.f;
+                    pd = keep ? pv * p.drop_scale : 0.f;
+                }
+                sacc[r] = pd;                      // dropped weights feed dV
+                pacc[r] = pv * (dp - tX[rr]);      // dS uses the undropped P
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)

@@ -129,9 +129,6 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
                            "(there is deliberately no CPU fallback)")
     if query.dtype not in _DTYPES:
         raise NotImplementedError(f"dtype {query.dtype}: supported are torch.float16, torch.bfloat16 and torch.float32")
-    if query.dtype == torch.float32 and (mask is not None or bias is not None or (dropout_p and dropout_p > 0)):
-        raise NotImplementedError("fp32 inputs run on the exact-fp32 MFMA kernels, which cover plain and causal attention; "
-                                  "attn_mask, attn_bias and dropout need fp16/bf16 inputs")
     if key.dtype != query.dtype or value.dtype != query.dtype:
         raise TypeError("query, key and value must share one dtype")
     dropout_p = float(dropout_p or 0.0)

@@ -46,8 +46,8 @@ extern "C" {
 #define FASN_EUNSUPPORTED (-7)/* valid request this build does not implement (e.g. dropout) */
 #define FASN_EWORKSPACE (-8)  /* workspace missing or too small */
 
-/* element types of q/k/v/o/do/dq/dk/dv (FASN_DTYPE_F32 = 2, defined below: exact-fp32 MFMA kernels, plain and causal
-   attention only - mask, bias and dropout need a 16-bit type) */
+/* element types of q/k/v/o/do/dq/dk/dv (FASN_DTYPE_F32 = 2, defined below: exact-fp32 MFMA kernels; with fp32 q/k/v the
+   bias, if any, is fp32 too and mask / bias / dropout take an element-load instantiation) */
 #define FASN_DTYPE_F16 0
 #define FASN_DTYPE_BF16 1
 

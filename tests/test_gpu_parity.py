@@ -341,8 +341,6 @@ def test_real_valued_n_and_signature_aliases(pkg, dev):
         pkg.flash_attention_n(q, k, v, dropout_p=1.0)
     with pytest.raises(NotImplementedError):
         pkg.flash_attention_n(q.double(), k.double(), v.double())
-    with pytest.raises(NotImplementedError):
-        pkg.flash_attention_n(q.float(), k.float(), v.float(), dropout_p=0.1)
 
 
 # ---------------------------------------------------------------- fp32 (exact-fp32 MFMA kernels)
@@ -384,6 +382,41 @@ def test_fp32_ragged_sizes_and_golden(pkg, dev, golden_dir, shape, causal):
     go.backward(torch.from_numpy(g["dout"]).to(dev))
     for got, name in ((go, "o"), (gq.grad, "dq"), (gk.grad, "dk"), (gv.grad, "dv")):
         assert np.abs(got.detach().cpu().numpy() - g[f"{name}_{tag}"]).max() <= 5e-6
+
+
+@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("kind", ["keypad", "dense", "bias3d", "all", "all+dropout"])
+def test_fp32_mask_bias_dropout(pkg, dev, kind, D):
+    """fp32 inputs with attn_mask / attn_bias / dropout (the reference's fp32 grid includes dropout_p = 0.2,
+    tests/gpu/core/test_flash_attn.py:11-15): exact-fp32 kernels, element-load general instantiation"""
+    B, H, L, S = 2, 2, 150, 200
+    q, k, v = (_rand(sh, torch.float32, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), torch.float32, dev, 4, std=1.0)
+    gen = torch.Generator().manual_seed(5)
+    mask = bias = None
+    causal = kind.startswith("all")
+    if kind in ("keypad", "all", "all+dropout"):
+        mask = synth.keypad_mask(B, S, device=dev)
+    if kind == "dense":
+        mask = (torch.rand(B, H, L, S, generator=gen) < 0.7).to(dev)
+        mask[..., 0] = True
+    if kind in ("bias3d", "all", "all+dropout"):
+        bias = torch.randn(H, L, S, generator=gen).to(dev)
+    p = 0.2 if kind == "all+dropout" else 0.0
+    torch.manual_seed(77)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, attn_mask=mask, attn_bias=bias, is_causal=causal, dropout_p=p)
+    assert out.dtype == torch.float32
+    out.backward(do)
+    if p:
+        keep = pkg.dropout.keep_mask(pkg.flash_attn._attention.last_seed, 0, B, H, L, S, p)
+        o, dq, dk, dv = _oracle_dropout(q, k, v, do, keep, pkg.dropout.effective_p(p), softmax_n_param=0.5, is_causal=causal,
+                                        attn_mask=mask.cpu(), attn_bias=bias.cpu())
+    else:
+        o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=0.5, attn_mask=mask, is_causal=causal, attn_bias=bias)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        err = (got.detach().cpu() - want).abs().max().item()
+        assert err <= 1e-3, f"{kind}/{nm}: {err:.3e} > reference atol 1e-3"
+        assert err <= 5e-5 * max(want.abs().max().item(), 1.0), f"{kind}/{nm}: {err:.3e}"
 
 
 # ---------------------------------------------------------------- dropout
