@@ -129,7 +129,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     l.D = a->D;
     if (a->mask.ptr || a->bias.ptr) {
         const bool vec = (!a->bias.ptr || p.bias_vec) && (!a->mask.ptr || p.mask_vec);
-        l.mode = (!vec || p.drop_thr) ? MODE_GENERAL_SLOW : (a->bias.ptr && a->mask.ptr) ? MODE_GENERAL : a->bias.ptr ? MODE_GENERAL_B : MODE_GENERAL_M;
+        l.mode = !vec ? MODE_GENERAL_SLOW : (a->bias.ptr && a->mask.ptr) ? MODE_GENERAL : a->bias.ptr ? MODE_GENERAL_B : MODE_GENERAL_M;
     } else {
         l.mode = a->causal ? MODE_CAUSAL : MODE_PLAIN;
     }

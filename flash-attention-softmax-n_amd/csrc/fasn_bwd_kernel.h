@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                         float dp = pacc[qb][kb][r];
                         if (DROP) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
                             const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row);
-                            const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)((k0 + kb * 32 + 8 * (r >> 2) + 4 * hi) >> 2));
+                            const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)((k0 + kb * 32 + (VEC ? 16 * hi + 4 * (r >> 2) : 8 * (r >> 2) + 4 * hi)) >> 2));
                             dp = drop_keep(hsh, r & 3, p.drop_thr) ? dp * p.drop_scale : 0.f;
                         }
                         sacc[qb][kb][r] = pv * (dp - dlt[qb]);

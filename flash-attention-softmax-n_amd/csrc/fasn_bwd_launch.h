@@ -49,7 +49,8 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
         switch (mode) {
             case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K, 1>(p, s);
             case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K, 1>(p, s);
-            default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1, 1>(p, s);
+            case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1, 1>(p, s);
+            default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 1>(p, s);   // vector mask / bias
         }
     }
     switch (mode) {

@@ -430,8 +430,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             // dropout of the 8 weights of (qb, kb, t2): keys k0 + kb*32 + 16*t2 + 4*hi + {0..3} and + 8 + {0..3}
             auto drop8 = [&](f32x8& x, int qb, int kb, int t2) {
                 const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)(qw0 + qb * 32 + l31));
-                const uint32_t kq = (uint32_t)((k0 + kb * 32 + 16 * t2 + 4 * hi) >> 2);
-                const uint32_t h0 = drop_hash(rb, p.seed_hi, kq), h1 = drop_hash(rb, p.seed_hi, kq + 2);
+                // registers 8*t2 + {0..3} and + {4..7} are two groups of 4 consecutive keys: 8 apart in the plain layout,
+                // adjacent in the key-permuted layout of the vector general modes
+                const uint32_t kq = (uint32_t)((k0 + kb * 32 + (KPERM ? 16 * hi + 8 * t2 : 16 * t2 + 4 * hi)) >> 2);
+                const uint32_t h0 = drop_hash(rb, p.seed_hi, kq), h1 = drop_hash(rb, p.seed_hi, kq + (KPERM ? 1 : 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     x[e] = drop_keep(h0, e, p.drop_thr) ? x[e] : 0.f;

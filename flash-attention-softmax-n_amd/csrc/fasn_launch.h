@@ -202,10 +202,26 @@ int launch_fwd_drop_one(FwdParams p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
+// dropout + vector mask / bias (the usual fine-tuning setting: padding mask + attention dropout): MODE_GENERAL serves all
+// three mask / bias combinations (an absent operand is a zero-range descriptor / an all-ones word)
+template <typename Tag, int D, int OCC, int NW, int RING>
+int launch_fwd_drop_gen(FwdParams p, hipStream_t s) {
+    constexpr int BM = NW * 32;
+    constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2 + NW * 6144;
+    p.nqblk = (p.Sq + BM - 1) / BM;
+    auto kern = fasn_fwd_kernel<Tag, D, 1, MODE_GENERAL, OCC, NW, 0, 0, 1, RING>;
+    set_smem_attr(kern, smem);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(NW * 64), smem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
 template <typename Tag, int D, int QB, int OCC>
 int launch_fwd_drop(const FwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_PLAIN) return launch_fwd_drop_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
     if (mode == MODE_CAUSAL) return launch_fwd_drop_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
+    if (mode == MODE_GENERAL || mode == MODE_GENERAL_B || mode == MODE_GENERAL_M) {
+        if constexpr (D == 128) return launch_fwd_drop_gen<Tag, D, 2, 8, 2>(p, s);
+        else return launch_fwd_drop_gen<Tag, D, D == 32 ? 1 : 2, 4, 0>(p, s);
+    }
     return launch_fwd_drop_one<Tag, D, QB, MODE_GENERAL_SLOW, 1>(p, s);
 }
 
