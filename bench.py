@@ -101,7 +101,7 @@ def main():
                  None if bias is None else bias.unsqueeze(0).expand(B, H, S, S), n, 1.0 / D ** 0.5, causal)
     ms = ctypes.c_float(0.0)
     stream = torch.cuda.current_stream().cuda_stream
-    pkg._lib.check(pkg._lib.load().fasn_time_fwd(a, stream, 3, max(10, args.steps), ctypes.byref(ms)), "fasn_time_fwd")
+    pkg._lib.check(pkg._lib.load().fasn_time_fwd(a, stream, 10, max(200, args.steps), ctypes.byref(ms)), "fasn_time_fwd")
     kernel_ms = float(ms.value)
     flops = fwd_flops(B, H, S, D, causal)
     achieved = flops / (kernel_ms * 1e-3) / 1e12
