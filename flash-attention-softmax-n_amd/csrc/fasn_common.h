@@ -127,9 +127,10 @@ FASN_DEV typename E::vec8 lds_read_trfrag(const char* tile, int rbase, int cblk,
 // 16 bytes per lane straight from a buffer into LDS: LDS byte address = lds_base + 16*lane (lds_base wave-uniform, goes to
 // M0), global address = descriptor base + voff + soff. Written as inline asm on purpose: for the builtin the compiler
 // tracks the LDS write and puts `s_waitcnt vmcnt(0)` in front of later LDS reads it cannot prove disjoint, which would
-// serialise the prefetch; here the caller owns the `s_waitcnt vmcnt(N)` + barrier that publishes the data.
+// serialise the prefetch; here the caller owns the `s_waitcnt vmcnt(N)` + barrier that publishes the data. The s_nop is the
+// wait state the ISA asks for between an SALU write of M0 and an LDS-DMA instruction (the compiler emits the same).
 FASN_DEV void lds_dma16(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t soff) {
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
                  : "memory", "m0");
 }
 // raw buffer descriptor (stride 0, range-checked on `bytes`) as four SGPR words
