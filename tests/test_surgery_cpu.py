@@ -13,24 +13,24 @@ from oracle.ref_attention import analytic_answer, ref_attention_n
 import flash_attention_softmax_n_amd.surgery as surgery
 from flash_attention_softmax_n_amd.surgery import PolicyRegistry, apply_attention_softmax_n, policy_registry
 
-SCALE, FACTOR = 0.2, 2.0
+LOGIT_SCALE, GAIN = 0.2, 2.0
 
 
-class DoubleAttention(Module):
+class TwiceAttention(Module):
     """2 x softmax_0 attention (the reference test's dummy module, tests/cpu/surgery/test_register.py:26-35)"""
 
     def __init__(self):
         super().__init__()
-        self.factor = FACTOR
+        self.gain = GAIN
 
     def forward(self, q: Tensor, k: Tensor, v: Tensor) -> Tensor:
-        return self.factor * ref_attention_n(q, k, v, softmax_n_param=0.0, scale=SCALE)
+        return self.gain * ref_attention_n(q, k, v, softmax_n_param=0.0, scale=LOGIT_SCALE)
 
 
-class DummyModel(Module):
+class TinyNet(Module):
     def __init__(self):
         super().__init__()
-        self.attn = DoubleAttention()
+        self.attn = TwiceAttention()
         self.other = Linear(4, 4)
 
     def forward(self, q, k, v):
@@ -38,7 +38,7 @@ class DummyModel(Module):
 
 
 def _new_forward(self, q: Tensor, k: Tensor, v: Tensor) -> Tensor:
-    return self.factor * ref_attention_n(q, k, v, softmax_n_param=self.n, scale=SCALE)
+    return self.gain * ref_attention_n(q, k, v, softmax_n_param=self.n, scale=LOGIT_SCALE)
 
 
 @pytest.fixture
@@ -53,7 +53,7 @@ def clean_registry():
 def test_register_and_apply(clean_registry, weight):
     seen = []
 
-    @policy_registry.register(DoubleAttention)
+    @policy_registry.register(TwiceAttention)
     def converter(module: Module, module_index: int, softmax_n_param: float) -> Module:
         seen.append(module_index)
         module.n = softmax_n_param
@@ -61,14 +61,14 @@ def test_register_and_apply(clean_registry, weight):
         return module
 
     N, L, S, E = 2, 3, 5, 8
-    model = DummyModel()
+    model = TinyNet()
     q, k, v = (weight * torch.ones(N, sz, E) for sz in (L, S, S))
     before = model(q, k, v)
-    assert torch.allclose(before, torch.full_like(before, FACTOR * analytic_answer(weight, S, E, SCALE, 0.0)), atol=1e-5)
+    assert torch.allclose(before, torch.full_like(before, GAIN * analytic_answer(weight, S, E, LOGIT_SCALE, 0.0)), atol=1e-5)
     assert apply_attention_softmax_n(model, softmax_n_param=2.0) == 1
     assert seen == [0] and model.attn.n == 2.0
     after = model(q, k, v)
-    assert torch.allclose(after, torch.full_like(after, FACTOR * analytic_answer(weight, S, E, SCALE, 2.0)), atol=1e-5)
+    assert torch.allclose(after, torch.full_like(after, GAIN * analytic_answer(weight, S, E, LOGIT_SCALE, 2.0)), atol=1e-5)
 
 
 def test_registry_rejects_bad_surgery_functions():
@@ -76,7 +76,7 @@ def test_registry_rejects_bad_surgery_functions():
     with pytest.raises(ValueError):
         reg.register()
     with pytest.raises(ValueError):
-        reg.register(DoubleAttention)(lambda module, module_index: module)
+        reg.register(TwiceAttention)(lambda module, module_index: module)
 
     def bad_first(module: int, module_index: int, softmax_n_param: float):
         return None
@@ -95,23 +95,23 @@ def test_registry_rejects_bad_surgery_functions():
 
     for f, err in ((bad_first, TypeError), (bad_second, TypeError), (bad_third, TypeError), (bad_name, NameError)):
         with pytest.raises(err):
-            reg.register(DoubleAttention)(f)
+            reg.register(TwiceAttention)(f)
     with pytest.raises(TypeError):
         reg.register(int)(good)
-    reg.register(DoubleAttention)(good)
+    reg.register(TwiceAttention)(good)
     with pytest.raises(ValueError):
-        reg.register(DoubleAttention)(good)
-    assert reg[DoubleAttention] is good
+        reg.register(TwiceAttention)(good)
+    assert reg[TwiceAttention] is good
 
 
 def test_no_match_warns_and_none_result_keeps_module(clean_registry, caplog):
     policy_registry.clear()
-    model = DummyModel()
+    model = TinyNet()
     with caplog.at_level(logging.WARNING, logger=surgery.__name__):
         assert apply_attention_softmax_n(model, 1.0) == 0
     assert "had no effect" in caplog.text
 
-    @policy_registry.register(DoubleAttention)
+    @policy_registry.register(TwiceAttention)
     def declines(module: Module, module_index: int, softmax_n_param: float):
         return None
 
@@ -124,7 +124,7 @@ def test_replacement_module_and_optimizer_params(clean_registry):
     def widen(module: Module, module_index: int, softmax_n_param: float) -> Module:
         return Linear(module.in_features, module.out_features, bias=False)
 
-    model = DummyModel()
+    model = TinyNet()
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
     old_params = list(model.other.parameters())
     assert apply_attention_softmax_n(model, 1.0, optimizers=opt) == 1
