@@ -29,6 +29,10 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.variant == 6) return launch_fwd_pipe_mode<Tag, 128, 1, 1>(p, l.mode, s);
     if (l.variant == 50) return launch_fwd_split<Tag, 128, 1, 2>(p, l.mode, s);   // 32-key sub-tiles
     if (l.variant == 51) return launch_fwd_split<Tag, 128, 1, 1>(p, l.mode, s);
+    if (l.variant == 62) return launch_fwd_pipe_mode<Tag, 128, 1, 1, 3>(p, l.mode, s);   // hand-ordered pipelined block, one wave per SIMD
+    if (l.variant == 64) return launch_fwd_pipe_mode<Tag, 128, 1, 1, 4>(p, l.mode, s);   //   ablation: no staging
+    if (l.variant == 65) return launch_fwd_pipe_mode<Tag, 128, 1, 1, 5>(p, l.mode, s);   //   ablation: no staging, no barrier
+    if (l.variant == 68) return launch_fwd_pipe_mode<Tag, 128, 1, 1, 6>(p, l.mode, s);   //   ablation: + no LDS fragment reads
     if (l.variant == 31) return launch_fwd_abl8<Tag, 128, 1, 2, 1>(p, s);   // 8-wave ablations: no exp
     if (l.variant == 33) return launch_fwd_abl8<Tag, 128, 1, 2, 3>(p, s);   //   no PV MFMAs
     if (l.variant == 35) return launch_fwd_abl8<Tag, 128, 1, 2, 5>(p, s);   //   no LDS fragment reads

@@ -26,7 +26,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         //   plain : QB=2 / 2 waves per SIMD / two-set K/V ring  977 TFLOP/s  (single set 957, QB=1 / 3 waves 899-928)
         //   causal: QB=1 / 3 waves per SIMD / ring             728 TFLOP/s  (QB=2 686: coarser diagonal, worse tail)
         const long blocks_qb2 = (long)((p.Sq + 255) / 256) * p.B * p.H;
-        v = (l.mode == MODE_PLAIN && blocks_qb2 >= 512) ? 40 : 41;   // 512 = one full round of two workgroups per CU (C2: 791 vs 731 TFLOP/s)
+        v = (l.mode == MODE_PLAIN && blocks_qb2 >= 512 && p.Sq >= 256) ? 40 : 41;   // 512 = one full round of two workgroups per CU (C2: 791 vs 731 TFLOP/s)
     }
     switch (v) {
         // ---- production tuning points

@@ -329,7 +329,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 
     // one K/V tile; LSET = register set that receives the prefetch issued here, SSET = set written to LDS at the end
     auto tile_body = [&](const int t, auto LSET, auto SSET) {
-        const int buf = (ABL == 6 || ABL == 7) ? 0 : (RING == 2 ? t % 3 : (t & 1));
+        // RING 1: the loop is unrolled by two (even tile: LSET = set 0, odd tile: LSET = set 1), so the LDS buffer index is a
+        // compile-time constant there and buf*TILEB folds into the ds_read immediate offsets instead of two VALU per read
+        const int buf = (ABL == 6 || ABL == 7) ? 0 : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1)));
         const int k0 = t * KT;
         if (RING == 2 && !VEC) stage_direct(t + 2, (t + 2) % 3);   // past-the-end tiles are out of range for the descriptor
         else if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
@@ -342,7 +344,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             need_mask = (k0 + KT - 1) > wave_first_vis;
         }
         if (k0 + KT > p.Sk) need_mask = true;
-        if (qw0 >= p.Sq) skip = true;   // short query blocks (decode shapes): a wave without rows only helps staging the tiles
+        // short query blocks (decode shapes): a wave without rows only helps staging the tiles (QB = 1 kernels: the QB = 2
+        // ones are only dispatched for Sq >= 256 and keep their register allocation)
+        if ((QB == 1 || SPLIT) && qw0 >= p.Sq) skip = true;
 
         // VEC: mask bytes of this lane's elements, 4 consecutive keys per load; SLOW: every tile takes the exact path
         uint32_t mraw[QB][2][4];

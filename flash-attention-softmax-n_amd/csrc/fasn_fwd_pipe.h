@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
         bool bad = false;
 
         if (BURST >= 3 && !need_mask) {
-            // ---- hand-ordered block (QB = 1): 16 groups, each = one MFMA (PV of tile t-1, then QK^T of tile t+1), the LDS
+            // ---- hand-ordered block (QB = 1): one group per MFMA (PV of tile t-1, then QK^T of tile t+1; 16 at D=64, 32 at D=128), the LDS
             // fragment read of the MFMA four groups later, and the softmax arithmetic of two elements per lane of tile t,
             // skewed over three groups (packed fma | two exponentials | packed add + packed convert) so no instruction
             // waits on the one in front of it. sched_barrier(0) pins the order: an in-order wave overlaps an MFMA only
@@ -210,16 +210,19 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
             const f32x2 c2 = {p.c, p.c}, m2 = {-m_run[0], -m_run[0]};
             f32x2 rs2 = {0.f, 0.f};
             f32x2 tq[2], xq[2];   // pk_fma results / exponentials in flight, indexed by pair parity
+            // MFMA j of the block: j < NPV: PV(t-1), accumulators (d) alternating fastest; then QK^T(t+1), the two key blocks alternating
+            constexpr int NPV = 4 * DB, NQK = 2 * KS, NM = NPV + NQK, VSTEP = NM / 16;   // one softmax pair every VSTEP groups
             auto ds = [&](int j) {
-                if (BURST == 6 || BURST == 7) { fr[j % NF] = qf[0][j & 3]; asm volatile("" : "+v"(fr[j % NF])); return; }   // ablation: no LDS reads
-                if (j < 8) fr[j % NF] = lds_read_trfrag<E, D>(tVp, (j >> 2) * 32 + 16 * ((j >> 1) & 1), j & 1, lane);
-                else fr[j % NF] = lds_read_rowfrag<E, D>(tKn, ((j - 8) & 1) * 32 + l31, (j - 8) >> 1, hi);
+                if (BURST == 6 || BURST == 7) { fr[j % NF] = qf[0][j % KS]; asm volatile("" : "+v"(fr[j % NF])); return; }   // ablation: no LDS reads
+                if (j < NPV) fr[j % NF] = lds_read_trfrag<E, D>(tVp, ((j / DB) >> 1) * 32 + 16 * ((j / DB) & 1), j % DB, lane);
+                else fr[j % NF] = lds_read_rowfrag<E, D>(tKn, ((j - NPV) & 1) * 32 + l31, (j - NPV) >> 1, hi);
             };
             auto mm = [&](int j) {
-                if (j < 8) {
-                    oacc[0][j & 1] = E::mfma(fr[j % NF], pf[C ^ 1][0][j >> 2][(j >> 1) & 1], oacc[0][j & 1]);
+                if (j < NPV) {
+                    const int d = j % DB, kt = j / DB;   // kt = kb*2 + t2
+                    oacc[0][d] = E::mfma(fr[j % NF], pf[C ^ 1][0][kt >> 1][kt & 1], oacc[0][d]);
                 } else {
-                    const int kb = (j - 8) & 1, ks = (j - 8) >> 1;   // alternate the two accumulators
+                    const int kb = (j - NPV) & 1, ks = (j - NPV) >> 1;
                     f32x16 z;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) z[r] = 0.f;
@@ -257,12 +260,15 @@ __global__ void __launch_bounds__(256, OCC) fasn_fwd_pipe_kernel(const FwdParams
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                mm(i);
-                if (i + NF < 16) ds(i + NF);
-                v_out(i + LEAD - 2);
-                v_exp(i + LEAD - 1);
-                v_fma(i + LEAD);
+            for (int g = 0; g < NM; ++g) {
+                mm(g);
+                if (g + NF < NM) ds(g + NF);
+                if (g % VSTEP == 0) {
+                    const int i = g / VSTEP;
+                    v_out(i + LEAD - 2);
+                    v_exp(i + LEAD - 1);
+                    v_fma(i + LEAD);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             v_out(15 + LEAD - 1);   // drain the skew

@@ -108,6 +108,15 @@ __global__ void __launch_bounds__(256, 2) kern(float* out, int iters) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             v_out(14); v_out(15);
+        } else if (ORDER == 7) {   // D = 128 density: 32 MFMAs per 16 pairs (two passes over the 16 MFMAs, softmax every other group)
+#pragma unroll
+            for (int i = -LEAD; i < 0; ++i) { v_out(i + LEAD - 2); v_exp(i + LEAD - 1); v_fma(i + LEAD); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int g = 0; g < 32; ++g) {
+                mm(g & 15);
+                if ((g & 1) == 0) { const int i = g >> 1; v_out(i + LEAD - 2); v_exp(i + LEAD - 1); v_fma(i + LEAD); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else if (ORDER == 2) {   // batched by four: groups 4k, 4k+1: 4 exps each; groups 4k+2, 4k+3: packed ops of 4 pairs
             // pairs 4k..4k+3 exponentiated in groups 4k (pairs 4k,4k+1) and 4k+1 (4k+2,4k+3); out in 4k+2 / 4k+3; fma for the next four in 4k+2 / 4k+3
         }
@@ -153,6 +162,8 @@ int main() {
     run<127, 4>("everything, VALU first / MFMA last in a group", it);
     run<127, 5>("everything, compiler's order (MFMA burst, then VALU)", it);
     run<127, 6>("everything, groups of two MFMAs", it);
+    run<127, 7>("D=128 density: 32 MFMA + 32 elements (MFMA alone 2x)", it);
+    run<16, 7>("D=128 density: the 32 MFMAs alone", it);
     run<16 + 1 + 32, 1>("MFMA + exp only, batched", it);
     run<127 - 64>("everything, PV operand loop-invariant", it);
     run<127 - 32>("everything, VALU input loop-invariant", it);
