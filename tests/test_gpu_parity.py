@@ -641,3 +641,47 @@ def test_randomized_shapes_modes_and_layouts(pkg, dev, seed):
         return
     for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
         _check(got, want, dtype, f"{c} {nm}")
+
+
+# ---------------------------------------------------------------- streams and graphs
+def test_forward_backward_inside_a_hip_graph_and_on_side_streams(pkg, dev):
+    """the C ABI never allocates or synchronises and launches on the caller's stream: a forward + backward step can be captured
+    into a HIP graph and replayed with new inputs, and two side streams can run independent problems concurrently"""
+    dtype = torch.bfloat16
+    shape = (2, 4, 384, 64)
+    q, k, v = (_rand(shape, dtype, dev, s).requires_grad_() for s in (1, 2, 3))
+    do = _rand(shape, dtype, dev, 4, std=1.0)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):     # warm-up on a side stream, as graph capture requires
+        for _ in range(2):
+            out = pkg.flash_attention_n(q, k, v, softmax_n_param=1, is_causal=True)
+            out.backward(do)
+            q.grad = k.grad = v.grad = None
+    torch.cuda.current_stream(dev).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = pkg.flash_attention_n(q, k, v, softmax_n_param=1, is_causal=True)
+        out.backward(do)
+    # replay with different input VALUES in the captured buffers
+    with torch.no_grad():
+        q.copy_(_rand(shape, dtype, dev, 11))
+        k.copy_(_rand(shape, dtype, dev, 12))
+        v.copy_(_rand(shape, dtype, dev, 13))
+    g.replay()
+    torch.cuda.synchronize()
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0, is_causal=True)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"graph replay {nm}")
+    # two independent problems on two streams
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    a = [_rand((1, 8, 1024, 64), dtype, dev, s) for s in (21, 22, 23)]
+    b = [_rand((1, 8, 1024, 128), dtype, dev, s) for s in (31, 32, 33)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        oa = pkg.flash_attention_n(*a, softmax_n_param=0.5)
+    with torch.cuda.stream(s2):
+        ob = pkg.flash_attention_n(*b, softmax_n_param=2.0, is_causal=True)
+    torch.cuda.synchronize()
+    _check(oa, ref_attention_n(*(t.cpu().float() for t in a), softmax_n_param=0.5), dtype, "stream 1")
+    _check(ob, ref_attention_n(*(t.cpu().float() for t in b), softmax_n_param=2.0, is_causal=True), dtype, "stream 2")
