@@ -2,6 +2,6 @@
 #include "fasn_bwd_launch.h"
 namespace fasn {
 int launch_bwd_d128(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
-    return l.dtype == 1 ? launch_bwd_mode<bf16_tag, 128, 1, 1, 1, 1>(p, l.mode, s) : launch_bwd_mode<f16_tag, 128, 1, 1, 1, 1>(p, l.mode, s);
+    return l.dtype == 1 ? launch_bwd_mode<bf16_tag, 128, 1, 1, 2, 1>(p, l.mode, s) : launch_bwd_mode<f16_tag, 128, 1, 1, 2, 1>(p, l.mode, s);
 }
 }  // namespace fasn

@@ -101,13 +101,14 @@ struct TileStage {
 template <int D, int NLD>
 struct TileDma {
     unsigned voff[NLD];
-    FASN_DEV void init(int tid, int64_t row_stride) {
+    FASN_DEV void init(int tid, int64_t row_stride, bool kperm = false) {
         constexpr int CPR = D / 8;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int ci = tid + i * 256;
             const int row = ci / CPR, ch = (ci % CPR) ^ swz_f<D>(row);
-            voff[i] = (unsigned)(row * (int)row_stride * 2 + ch * 16);
+            const int grow = kperm ? ((row & ~31) | (((row >> 2) & 1) << 4) | (((row >> 3) & 3) << 2) | (row & 3)) : row;
+            voff[i] = (unsigned)(grow * (int)row_stride * 2 + ch * 16);
         }
     }
     FASN_DEV void dma(u32x4 rw, uint32_t tile_addr_wave, int row0, int64_t row_stride) const {
@@ -197,11 +198,27 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     TileStage<D, NLD> tsK, tsV;
     tsK.init(tid, p.ks[2], MODE == MODE_GENERAL);
     tsV.init(tid, p.vs[2], MODE == MODE_GENERAL);
+    // D = 128: K/V tiles go straight to LDS. With staging registers the S / dP accumulators do not fit in the 256 VGPRs next to
+    // the Q and dO fragments, the compiler parks them in AGPRs and pays ~130 v_accvgpr moves per tile to use them.
+    constexpr bool DIRECT = D == 128 && MODE != MODE_GENERAL_SLOW;
+    TileDma<D, NLD> tdK, tdV;
+    const u32x4 krw = make_rsrc_words(kbase, p.kbytes), vrw = make_rsrc_words(vbase, p.vbytes);
+    const uint32_t ldsK_w = lds_addr(ldsK) + wave * 1024, ldsV_w = lds_addr(ldsV) + wave * 1024;
+    if (DIRECT) {
+        tdK.init(tid, p.ks[2], MODE == MODE_GENERAL);
+        tdV.init(tid, p.vs[2], MODE == MODE_GENERAL);
+    }
     if (ntiles > 0) {
-        tsK.gload(stK, krs, 0, p.ks[2]);
-        tsV.gload(stV, vrs, 0, p.vs[2]);
-        tsK.lstore(stK, ldsK);
-        tsV.lstore(stV, ldsV);
+        if (DIRECT) {
+            tdK.dma(krw, ldsK_w, 0, p.ks[2]);
+            tdV.dma(vrw, ldsV_w, 0, p.vs[2]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            tsK.gload(stK, krs, 0, p.ks[2]);
+            tsV.gload(stV, vrs, 0, p.vs[2]);
+            tsK.lstore(stK, ldsK);
+            tsV.lstore(stV, ldsV);
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -284,8 +301,16 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             gen_dma(t + 1);                          // past-the-end tiles are out of range: zeros
-            tsK.gload(stK, krs, k0 + KT, p.ks[2]);   // past-the-end tiles read back as zeros
-            tsV.gload(stV, vrs, k0 + KT, p.vs[2]);
+            if (DIRECT) {
+                tdK.dma(krw, ldsK_w + (buf ^ 1) * TILEB, k0 + KT, p.ks[2]);
+                tdV.dma(vrw, ldsV_w + (buf ^ 1) * TILEB, k0 + KT, p.vs[2]);
+            } else {
+                tsK.gload(stK, krs, k0 + KT, p.ks[2]);   // past-the-end tiles read back as zeros
+                tsV.gload(stV, vrs, k0 + KT, p.vs[2]);
+            }
+        } else if (DIRECT) {   // buffer buf^1 was released by the barrier that ended the previous tile
+            tdK.dma(krw, ldsK_w + (buf ^ 1) * TILEB, k0 + KT, p.ks[2]);
+            tdV.dma(vrw, ldsV_w + (buf ^ 1) * TILEB, k0 + KT, p.vs[2]);
         } else if (t + 1 < ntiles) {
             tsK.gload(stK, krs, k0 + KT, p.ks[2]);
             tsV.gload(stV, vrs, k0 + KT, p.vs[2]);
@@ -301,87 +326,83 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         if (!skip) {
             const char* tK = ldsK + buf * TILEB;
             const char* tV = ldsV + buf * TILEB;
-            f32x16 sacc[QB][2], pacc[QB][2];
+            // one 32-key block at a time: S and dP (2*KS MFMAs per query block), then their element pass, so only ONE block's
+            // accumulators (2 x 16 registers per query block) are live at a time and block 1's MFMAs run under block 0's arithmetic
+            vec8 dsf[QB][2][2];
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 sacc[QB], pacc[QB];
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         if (VEC) {
                             const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
                             const float v = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * binv;
-                            sacc[qb][kb][r] = ((mraw[qb][kb][r >> 2] >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
+                            sacc[qb][r] = ((mraw[qb][kb][r >> 2] >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
                         } else {
-                            sacc[qb][kb][r] = 0.f;
+                            sacc[qb][r] = 0.f;
                         }
-                        pacc[qb][kb][r] = 0.f;
+                        pacc[qb][r] = 0.f;
                     }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
                     vec8 vf = lds_read_rowfrag<E, D>(tV, kb * 32 + l31, s, hi);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
-                        sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
-                        pacc[qb][kb] = E::mfma(vf, dof[qb][s], pacc[qb][kb]);
+                        sacc[qb] = E::mfma(kf, qf[qb][s], sacc[qb]);
+                        pacc[qb] = E::mfma(vf, dof[qb][s], pacc[qb]);
                     }
                 }
-
-            vec8 dsf[QB][2][2];
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const int row = qw0 + qb * 32 + l31;
-                const int vis = causal ? (row + coff) : 0x7fffffff;
-                auto elems = [&](auto MASKED) {
+                for (int qb = 0; qb < QB; ++qb) {
+                    const int row = qw0 + qb * 32 + l31;
+                    const int vis = causal ? (row + coff) : 0x7fffffff;
+                    auto elems = [&](auto MASKED) {
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float y = sacc[qb][kb][r] * p.c;
-                        bool show = true;
-                        if (decltype(MASKED)::value) {
-                            const int key = k0 + kb * 32 + (VEC ? 16 * hi + r : (r & 3) + 8 * (r >> 2) + 4 * hi);
-                            show = (key < p.Sk) && (key <= vis);
-                            if (MODE == MODE_GENERAL_SLOW) {
-                                const bool inb = show && (row < p.Sq);
-                                if (p.bias != nullptr && inb) {
-                                    const int64_t bo = b * p.bs[0] + h * p.bs[1] + (int64_t)row * p.bs[2] + (int64_t)key * p.bs[3];
-                                    float bv;
-                                    if (p.bias_f32) bv = reinterpret_cast<const float*>(p.bias)[bo];
-                                    else bv = E::to_f32(reinterpret_cast<const uint16_t*>(p.bias)[bo]);
-                                    y = __builtin_fmaf(bv, kLog2e, y);
-                                }
-                                if (p.mask != nullptr && inb) {
-                                    const int64_t mo = b * p.ms[0] + h * p.ms[1] + (int64_t)row * p.ms[2] + (int64_t)key * p.ms[3];
-                                    show = p.mask[mo] != 0;
+                        for (int r = 0; r < 16; ++r) {
+                            float y = sacc[qb][r] * p.c;
+                            bool show = true;
+                            if (decltype(MASKED)::value) {
+                                const int key = k0 + kb * 32 + (VEC ? 16 * hi + r : (r & 3) + 8 * (r >> 2) + 4 * hi);
+                                show = (key < p.Sk) && (key <= vis);
+                                if (MODE == MODE_GENERAL_SLOW) {
+                                    const bool inb = show && (row < p.Sq);
+                                    if (p.bias != nullptr && inb) {
+                                        const int64_t bo = b * p.bs[0] + h * p.bs[1] + (int64_t)row * p.bs[2] + (int64_t)key * p.bs[3];
+                                        float bv;
+                                        if (p.bias_f32) bv = reinterpret_cast<const float*>(p.bias)[bo];
+                                        else bv = E::to_f32(reinterpret_cast<const uint16_t*>(p.bias)[bo]);
+                                        y = __builtin_fmaf(bv, kLog2e, y);
+                                    }
+                                    if (p.mask != nullptr && inb) {
+                                        const int64_t mo = b * p.ms[0] + h * p.ms[1] + (int64_t)row * p.ms[2] + (int64_t)key * p.ms[3];
+                                        show = p.mask[mo] != 0;
+                                    }
                                 }
                             }
+                            float pv = (MODE == MODE_GENERAL_SLOW) ? fast_exp2(y - lse2[qb]) : fast_exp2(__builtin_fmaf(sacc[qb][r], p.c, -lse2[qb]));
+                            if (decltype(MASKED)::value) pv = show ? pv : 0.f;
+                            float dp = pacc[qb][r];
+                            if (DROP) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
+                                const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row);
+                                const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)((k0 + kb * 32 + (VEC ? 16 * hi + 4 * (r >> 2) : 8 * (r >> 2) + 4 * hi)) >> 2));
+                                dp = drop_keep(hsh, r & 3, p.drop_thr) ? dp * p.drop_scale : 0.f;
+                            }
+                            sacc[qb][r] = pv * (dp - dlt[qb]);
                         }
-                        float pv = (MODE == MODE_GENERAL_SLOW) ? fast_exp2(y - lse2[qb]) : fast_exp2(__builtin_fmaf(sacc[qb][kb][r], p.c, -lse2[qb]));
-                        if (decltype(MASKED)::value) pv = show ? pv : 0.f;
-                        float dp = pacc[qb][kb][r];
-                        if (DROP) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
-                            const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row);
-                            const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)((k0 + kb * 32 + (VEC ? 16 * hi + 4 * (r >> 2) : 8 * (r >> 2) + 4 * hi)) >> 2));
-                            dp = drop_keep(hsh, r & 3, p.drop_thr) ? dp * p.drop_scale : 0.f;
-                        }
-                        sacc[qb][kb][r] = pv * (dp - dlt[qb]);
-                    }
-                };
-                if (need_mask) elems(std::true_type{});
-                else elems(std::false_type{});
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                    };
+                    if (need_mask) elems(std::true_type{});
+                    else elems(std::false_type{});
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {
                         f32x8 x;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = sacc[qb][kb][8 * t2 + e];
+                        for (int e = 0; e < 8; ++e) x[e] = sacc[qb][8 * t2 + e];
                         dsf[qb][kb][t2] = E::cvt8(x);
                     }
+                }
             }
             // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
@@ -395,7 +416,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                         for (int qb = 0; qb < QB; ++qb) dqacc[qb][d] = E::mfma(ktf, dsf[qb][kb][t2], dqacc[qb][d]);
                     }
         }
-        if (VEC || t + 1 < ntiles) {
+        if (DIRECT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next K / V tiles have landed
+        } else if (VEC || t + 1 < ntiles) {
             tsK.lstore(stK, ldsK + (buf ^ 1) * TILEB);
             tsV.lstore(stV, ldsV + (buf ^ 1) * TILEB);
         }
@@ -512,7 +535,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     tsQ.init(tid, p.qs[2]);
     tsD.init(tid, bp.dos[2]);
     // vector general mode: Q / dO tiles go straight to LDS (the staging registers are needed for the additive tile)
-    constexpr bool DIRECT = MODE == MODE_GENERAL;
+    constexpr bool DIRECT = MODE == MODE_GENERAL || (D == 128 && MODE != MODE_GENERAL_SLOW);
     TileDma<D, NLD> tdQ, tdD;
     const u32x4 qrw = make_rsrc_words(qbase, bp.qbytes), drw = make_rsrc_words(dobase, bp.dobytes);
     const uint32_t ldsQ_w = lds_addr(smem) + wave * 1024, ldsDO_w = ldsQ_w + 2 * TILEB;
