@@ -77,6 +77,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 26: return launch_fwd_abl<Tag, 64, 2, 2, 6>(p, s);
         case 28: return launch_fwd_abl<Tag, 64, 2, 2, 8>(p, s);
         case 29: return launch_fwd_abl<Tag, 64, 2, 2, 9>(p, s);
+        case 20: return launch_fwd_abl<Tag, 64, 2, 2, 10>(p, s);
         default: break;
     }
     return launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);

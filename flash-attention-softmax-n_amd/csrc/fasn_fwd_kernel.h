@@ -69,7 +69,7 @@ constexpr float kSumLimit = 256.0f;
 
 // ABL (developer ablation, never dispatched by the ABI): 1 = no exponentials (P := raw S), 2 = no QK^T MFMAs,
 // 3 = no PV MFMAs, 4 = neither MFMA group, 5 = no K/V LDS fragment reads, 6 = no staging and no barrier,
-// 7 = 5 + 6, 8 = barrier but no staging, 9 = staging but no barrier
+// 7 = 5 + 6, 8 = barrier but no staging, 9 = staging but no barrier, 10 = staging always reads tile 0
 // DROP: attention-weight dropout compiled in (separate instantiations so the no-dropout kernels keep their registers).
 // RING: 1 = two staging register sets, K/V tiles are loaded TWO tiles ahead (the loop body is instantiated twice with the
 // sets swapped). One tile of lead is about 1.2 us at D=64, less than a first-touch HBM miss under load; in-order vmcnt
@@ -201,8 +201,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         constexpr int S_ = decltype(SET)::value;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            stK[S_][i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i], t * ktile_bytes, 0);
-            stV[S_][i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i], t * vtile_bytes, 0);
+            // ABL 10: every staging load fetches tile 0 (same instructions, always an L2 hit): separates instruction cost from memory latency
+            stK[S_][i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i], (ABL == 10 ? 0 : t) * ktile_bytes, 0);
+            stV[S_][i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i], (ABL == 10 ? 0 : t) * vtile_bytes, 0);
         }
     };
     auto stage_store = [&](int buf, auto SET) {
