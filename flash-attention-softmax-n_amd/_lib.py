@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasn.so")
 
-FASN_ABI_VERSION = 1
+FASN_ABI_VERSION = 2
 FASN_DTYPE_F16, FASN_DTYPE_BF16, FASN_DTYPE_F32 = 0, 1, 2
 FASN_BIAS_NONE, FASN_BIAS_SAME, FASN_BIAS_F32 = 0, 1, 2
 
@@ -43,6 +43,7 @@ class BwdArgs(Structure):
         ("fwd", FwdArgs),
         ("dout", View4), ("dq", View4), ("dk", View4), ("dv", View4),
         ("delta", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("dbias", View4),
     ]
 
 

@@ -279,6 +279,21 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
         p.qbytes = (unsigned)qb;
         p.dobytes = (unsigned)db;
     }
+    p.dbias = nullptr;
+    p.dbias_vec = 0;
+    for (int i = 0; i < 3; ++i) p.dbs[i] = 0;
+    if (a->dbias.ptr != nullptr) {
+        if (a->fwd.bias.ptr == nullptr) return FASN_EINVAL;   // nothing to differentiate
+        if (a->dbias.stride[3] != 1) return FASN_ESTRIDE;
+        if (reinterpret_cast<uintptr_t>(a->dbias.ptr) % esize) return FASN_EALIGN;
+        p.dbias = (char*)a->dbias.ptr;
+        bool vec = reinterpret_cast<uintptr_t>(a->dbias.ptr) % 16 == 0;
+        for (int i = 0; i < 3; ++i) {
+            p.dbs[i] = a->dbias.stride[i];
+            vec = vec && (a->dbias.stride[i] * esize) % 16 == 0;
+        }
+        p.dbias_vec = vec ? 1 : 0;
+    }
     for (int i = 0; i < 3; ++i) {
         p.dos[i] = a->dout.stride[i];
         p.dqs[i] = a->dq.stride[i];

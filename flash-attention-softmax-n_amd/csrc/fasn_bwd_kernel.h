@@ -33,6 +33,9 @@ struct BwdParams {
     float scale;
     unsigned qbytes, dobytes;  // byte extent of one (b,h) Q / dO matrix (buffer descriptor range)
     int nblk;  // blocks per head of the launching kernel
+    char* dbias;       // optional: dS written densely [B,H,Sq,Sk] (element type of q), key stride 1; nullptr = not wanted
+    int64_t dbs[3];
+    int dbias_vec;     // rows 16-byte aligned: 8 keys per store on the vector path
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -401,6 +404,30 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 #pragma unroll
                         for (int e = 0; e < 8; ++e) x[e] = sacc[qb][8 * t2 + e];
                         dsf[qb][kb][t2] = E::cvt8(x);
+                        // gradient of the additive bias = dS (only the mask / bias instantiations carry this code)
+                        if ((MODE == MODE_GENERAL || MODE == MODE_GENERAL_SLOW) && bp.dbias != nullptr && row < p.Sq) {
+                            char* drow = bp.dbias + (b * bp.dbs[0] + h * bp.dbs[1] + (int64_t)row * bp.dbs[2]) * 2;
+                            uint16_t hv[8];
+                            __builtin_memcpy(hv, &dsf[qb][kb][t2], 16);
+                            if (VEC) {   // registers 8*t2 .. 8*t2+7 = 8 consecutive keys
+                                const int key0 = k0 + kb * 32 + 16 * hi + 8 * t2;
+                                if (bp.dbias_vec && key0 + 8 <= p.Sk) {
+                                    u32x4 w;
+                                    __builtin_memcpy(&w, hv, 16);
+                                    gstore16(drow + key0 * 2, w);
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e)
+                                        if (key0 + e < p.Sk) *reinterpret_cast<uint16_t*>(drow + (key0 + e) * 2) = hv[e];
+                                }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const int r = 8 * t2 + e, key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                    if (key < p.Sk) *reinterpret_cast<uint16_t*>(drow + key * 2) = hv[e];
+                                }
+                            }
+                        }
                     }
                 }
             }

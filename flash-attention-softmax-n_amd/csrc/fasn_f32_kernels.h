@@ -345,6 +345,8 @@ __global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
                 float dp = pacc[kb][r];
                 if (GEN && p.drop_thr) dp = f32_keep(p, bh, row, key) ? dp * p.drop_scale : 0.f;
                 sacc[kb][r] = pv * (dp - dlt);   // dS^T (without the scale factor)
+                if (GEN && bp.dbias != nullptr && ok && key < p.Sk)
+                    reinterpret_cast<float*>(bp.dbias)[b * bp.dbs[0] + h * bp.dbs[1] + (int64_t)row * bp.dbs[2] + key] = sacc[kb][r];
             }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)

@@ -114,9 +114,17 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         a.delta = delta.data_ptr()
         a.workspace = None
         a.workspace_bytes = 0
+        # gradient of attn_bias: the kernel writes dS densely; autograd sums it over the dimensions the caller's bias broadcasts
+        # (the expand / unsqueeze / dtype cast in _attention are ordinary autograd ops)
+        dbias = None
+        if bias is not None and ctx.needs_input_grad[4]:
+            dbias = torch.zeros((B, H, L, S), dtype=q.dtype, device=q.device)   # tiles the causal walk skips are never written
+            a.dbias = _view4(dbias)
         with torch.cuda.device(q.device):
             _lib.check(lib.fasn_bwd(a, _stream_ptr(q.device)), "fasn_bwd")
-        return dq, dk, dv, None, None, None, None, None, None, None
+        if dbias is not None and dbias.dtype != bias.dtype:
+            dbias = dbias.to(bias.dtype)
+        return dq, dk, dv, None, dbias, None, None, None, None, None
 
 
 def _pad_feature(t: Tensor, d: int) -> Tensor:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FASN_ABI_VERSION 1
+#define FASN_ABI_VERSION 2
 
 /* error codes */
 #define FASN_OK 0
@@ -103,6 +103,8 @@ typedef struct fasn_bwd_args {
     float* delta;      /* [B,H,Sq] fp32 scratch */
     void* workspace;
     size_t workspace_bytes;
+    fasn_view4 dbias;  /* optional out (ABI 2): gradient of the additive bias = dS, dense [B,H,Sq,Sk] in `dtype`, key stride 1;
+                          ptr NULL = not wanted. Needs fwd.bias; the caller sums over the dimensions its bias broadcasts. */
 } fasn_bwd_args;
 
 int fasn_abi_version(void);

@@ -685,3 +685,41 @@ def test_forward_backward_inside_a_hip_graph_and_on_side_streams(pkg, dev):
     torch.cuda.synchronize()
     _check(oa, ref_attention_n(*(t.cpu().float() for t in a), softmax_n_param=0.5), dtype, "stream 1")
     _check(ob, ref_attention_n(*(t.cpu().float() for t in b), softmax_n_param=2.0, is_causal=True), dtype, "stream 2")
+
+
+# ---------------------------------------------------------------- gradient of attn_bias
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("kind", ["hls", "b1ls_f32", "keys", "bhls+mask+causal"])
+@pytest.mark.parametrize("D", [64, 128])
+def test_attn_bias_gradient(pkg, dev, D, kind, dtype):
+    """a bias that requires grad gets dS summed over the dimensions it broadcasts (the reference's SDPA path differentiates its
+    additive mask the same way); vector path, element-load path (fp32 bias) and the fp32 kernels"""
+    B, H, L, S = 2, 3, 150, 203
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    gen = torch.Generator().manual_seed(9)
+    mask, causal = None, False
+    if kind == "hls":
+        bias = torch.randn(H, L, S, generator=gen).to(dtype)
+    elif kind == "b1ls_f32":
+        bias = torch.randn(B, 1, L, S, generator=gen)
+    elif kind == "keys":
+        bias = torch.randn(1, H, 1, S, generator=gen).to(dtype)
+    else:
+        bias = torch.randn(B, H, L, S, generator=gen).to(dtype)
+        mask = synth.keypad_mask(B, S, device=dev)
+        causal = True
+    bias = bias.to(dev).requires_grad_()
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, attn_bias=bias, attn_mask=mask, is_causal=causal)
+    out.backward(do)
+    assert bias.grad is not None and bias.grad.shape == bias.shape and bias.grad.dtype == bias.dtype
+    qc, kc, vc, bc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v, bias))
+    o = ref_attention_n(qc, kc, vc, softmax_n_param=0.5, attn_bias=bc, attn_mask=None if mask is None else mask.cpu(), is_causal=causal)
+    o.backward(do.cpu().float())
+    if dtype == torch.float32:
+        for got, want, nm in ((out, o, "out"), (q.grad, qc.grad, "dq"), (bias.grad, bc.grad, "dbias")):
+            err = (got.detach().cpu().float() - want).abs().max().item()
+            assert err <= 5e-5 * max(want.abs().max().item(), 1.0), f"{kind}/{nm}: {err:.3e}"
+    else:
+        for got, want, nm in ((out, o, "out"), (q.grad, qc.grad, "dq"), (k.grad, kc.grad, "dk"), (bias.grad, bc.grad, "dbias")):
+            _check(got, want, dtype, f"{kind}/{nm}")
