@@ -79,6 +79,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     p.bias_f32 = (a->bias.ptr && (a->bias_dtype == FASN_BIAS_F32 || esize == 4)) ? 1 : 0;
     p.bias_vec = 0;
     p.mask_vec = 0;
+    p.keypad_fallback = 0;
     p.batch_inner = 0;
     if (a->bias.ptr) {
         const int esz = p.bias_f32 ? 4 : 2;
@@ -130,6 +131,11 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     if (a->mask.ptr || a->bias.ptr) {
         const bool vec = (!a->bias.ptr || p.bias_vec) && (!a->mask.ptr || p.mask_vec);
         l.mode = !vec ? MODE_GENERAL_SLOW : (a->bias.ptr && a->mask.ptr) ? MODE_GENERAL : a->bias.ptr ? MODE_GENERAL_B : MODE_GENERAL_M;
+        // key-padding mask (one byte per key for the whole (b,h), no bias): plain kernels + a per-tile visibility word
+        if (a->mask.ptr && !a->bias.ptr && a->mask.stride[2] == 0 && a->mask.stride[3] == 1) {
+            p.keypad_fallback = l.mode;   // what the backward (and split-K) use until they have their own key-padding path
+            l.mode = MODE_KEYPAD;
+        }
     } else {
         l.mode = a->causal ? MODE_CAUSAL : MODE_PLAIN;
     }
@@ -146,6 +152,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
 int plan_splitk(const fasn_fwd_args* a, const FwdParams& p, const FwdLaunch& l, int& tps) {
     tps = 0;
     if (l.dtype == FASN_DTYPE_F32 || p.drop_thr || l.mode == MODE_GENERAL_SLOW) return 1;
+    if (l.mode == MODE_KEYPAD && p.keypad_fallback == MODE_GENERAL_SLOW) return 1;
     const int64_t base_blocks = (int64_t)a->B * a->H * ((a->Sq + 127) / 128);
     int ntiles = (a->Sk + KT - 1) / KT;
     if (a->causal) {   // the last row's visible keys bound the walk
@@ -259,6 +266,7 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
     int rc = build_fwd(&a->fwd, fp, l);
     if (rc) return rc;
     if (a->fwd.lse == nullptr || a->delta == nullptr) return FASN_EINVAL;
+    if (l.mode == MODE_KEYPAD && l.dtype == FASN_DTYPE_F32) l.mode = MODE_GENERAL_SLOW;   // (the fp32 kernels have the element-load mask path only)
     const int esize = a->fwd.dtype == FASN_DTYPE_F32 ? 4 : 2;
     if ((rc = check_view(a->dout, true, esize))) return rc;
     if ((rc = check_view(a->dq, true, esize))) return rc;

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 
     int bh, qi;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
-    const bool causal = (MODE == MODE_CAUSAL) || ((MODE == MODE_GENERAL || MODE == MODE_GENERAL_SLOW) && p.causal);
+    const bool causal = (MODE == MODE_CAUSAL) || ((MODE == MODE_GENERAL || MODE == MODE_GENERAL_SLOW || MODE == MODE_KEYPAD) && p.causal);
     const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * BM;
@@ -281,9 +281,24 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     const int wave_first_vis = qw0 + coff;
     const int wave_last_vis = qw0 + QB * 32 - 1 + coff;
 
+    // MODE_KEYPAD (mask = one byte per key of the (b,h), no bias), as in the forward: each lane fetches the byte of key
+    // k0 + lane one tile ahead, a ballot makes the tile's visibility word; all-visible tiles are plain, all-hidden ones skipped
+    constexpr bool KP = MODE == MODE_KEYPAD;
+    __amdgpu_buffer_rsrc_t kprs;
+    uint32_t kp_next = 0;
+    if (KP) {
+        kprs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.mask + (b * p.ms[0] + h * p.ms[1])), 0, (unsigned)p.Sk, 0x00020000);
+        kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, 0, 0);
+    }
+
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         const int k0 = t * KT;
+        uint64_t kp_bits = ~0ull;
+        if (KP) {
+            kp_bits = __ballot(kp_next != 0);
+            kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
+        }
         uint32_t mraw[QB][2][4];
         u32x2 braw[QB][2][4];
         if (VEC) {   // unconditional, also for skipped tiles: the request / wait pattern is the same for every tile
@@ -325,6 +340,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         }
         if (k0 + KT > p.Sk) need_mask = true;
         if (MODE == MODE_GENERAL_SLOW) need_mask = true;
+        if (KP && kp_bits == 0) skip = true;
 
         if (!skip) {
             const char* tK = ldsK + buf * TILEB;
@@ -343,6 +359,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                             const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
                             const float v = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * binv;
                             sacc[qb][r] = ((mraw[qb][kb][r >> 2] >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
+                        } else if (KP) {   // bit (r&3) + 8(r>>2) + 4hi of this 32-key block
+                            const uint32_t w = (uint32_t)(kp_bits >> (32 * kb)) >> (4 * hi);
+                            sacc[qb][r] = ((w >> ((r & 3) + 8 * (r >> 2))) & 1u) ? 0.f : -INFINITY;
                         } else {
                             sacc[qb][r] = 0.f;
                         }
@@ -504,7 +523,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
 
     int bh, kblk;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
-    const bool causal = (MODE == MODE_CAUSAL) || ((MODE == MODE_GENERAL || MODE == MODE_GENERAL_SLOW) && p.causal);
+    const bool causal = (MODE == MODE_CAUSAL) || ((MODE == MODE_GENERAL || MODE == MODE_GENERAL_SLOW || MODE == MODE_KEYPAD) && p.causal);
     const int b = bh / p.H, h = bh % p.H;
     const int kw0 = kblk * BN + wave * (KB * 32);  // first key of this wave
     const int coff = p.Sk - p.Sq;
@@ -670,6 +689,19 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             retire_loads(vf[kb][s]);
         }
 
+    constexpr bool KPD = MODE == MODE_KEYPAD;
+    bool kp_keep[KB];
+    bool kp_none = false;
+    if (KPD) {
+        bool any = false;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int key = kw0 + kb * 32 + l31;
+            kp_keep[kb] = key < p.Sk && p.mask[b * p.ms[0] + h * p.ms[1] + key] != 0;
+            any = any || kp_keep[kb];
+        }
+        kp_none = !__any(any);
+    }
     for (int tq = tq0; tq < ntq; ++tq) {
         const int buf = (tq - tq0) & 1;
         const int r0 = tq * QT;
@@ -698,6 +730,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         }
         if (r0 + QT > p.Sq || kw0 + KB * 32 > p.Sk) need_mask = true;
         if (MODE == MODE_GENERAL_SLOW) need_mask = true;
+        if (KPD && kp_none) skip = true;   // none of this wave's keys is visible to anybody
 
         if (!skip) {
 #pragma unroll
@@ -717,8 +750,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                             for (int e = 0; e < 8; ++e) sacc[kb][8 * t2 + e] = E::to_f32(ab[e]) * binv;
                         }
                     } else {
+                        const float v0 = (KPD && !kp_keep[kb]) ? -INFINITY : 0.f;   // key-padding: a lane's key is hidden for every row
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+                        for (int r = 0; r < 16; ++r) sacc[kb][r] = v0;
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) pacc[kb][r] = 0.f;

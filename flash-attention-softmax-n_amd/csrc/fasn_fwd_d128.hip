@@ -13,7 +13,7 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (p.drop_thr) return launch_fwd_drop<Tag, 128, 1, 1>(p, l.mode, s);
-    if (l.mode >= MODE_GENERAL) return launch_gen<Tag>(p, l, s);
+    if (l.mode >= MODE_GENERAL && l.mode != MODE_KEYPAD) return launch_gen<Tag>(p, l, s);   // key-padding masks ride the plain tuning points
     if (l.variant == 1) return launch_fwd_mode<Tag, 128, 1, 1>(p, l.mode, s);
     // A/B and ablations (tools/fasn_harness bench ... <variant>); ablation results are not attention outputs
     if (l.variant == 40) return launch_fwd_ring<Tag, 128, 1, 2>(p, l.mode, s);

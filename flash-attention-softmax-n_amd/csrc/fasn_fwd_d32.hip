@@ -13,7 +13,7 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (p.drop_thr) return launch_fwd_drop<Tag, 32, 2, 2>(p, l.mode, s);
-    if (l.mode >= MODE_GENERAL) return launch_gen<Tag>(p, l, s);
+    if (l.mode >= MODE_GENERAL && l.mode != MODE_KEYPAD) return launch_gen<Tag>(p, l, s);
     return launch_fwd_mode<Tag, 32, 2, 2>(p, l.mode, s);
 }
 int launch_fwd_d32(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {

@@ -18,7 +18,7 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (p.drop_thr) return launch_fwd_drop<Tag, 64, 1, 2>(p, l.mode, s);
-    if (l.mode >= MODE_GENERAL) return launch_gen<Tag>(p, l, s);
+    if (l.mode >= MODE_GENERAL && l.mode != MODE_KEYPAD) return launch_gen<Tag>(p, l, s);   // key-padding masks ride the plain tuning points
     const bool gen = false;  // general modes returned above
     int v = l.variant;
     if (v == 0) {
@@ -26,7 +26,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         //   plain : QB=2 / 2 waves per SIMD / two-set K/V ring  977 TFLOP/s  (single set 957, QB=1 / 3 waves 899-928)
         //   causal: QB=1 / 3 waves per SIMD / ring             728 TFLOP/s  (QB=2 686: coarser diagonal, worse tail)
         const long blocks_qb2 = (long)((p.Sq + 255) / 256) * p.B * p.H;
-        v = (l.mode == MODE_PLAIN && blocks_qb2 >= 512 && p.Sq >= 256) ? 40 : 41;   // 512 = one full round of two workgroups per CU (C2: 791 vs 731 TFLOP/s)
+        v = ((l.mode == MODE_PLAIN || (l.mode == MODE_KEYPAD && !p.causal)) && blocks_qb2 >= 512 && p.Sq >= 256) ? 40 : 41;   // 512 = one full round of two workgroups per CU (C2: 791 vs 731 TFLOP/s)
     }
     switch (v) {
         // ---- production tuning points

@@ -29,7 +29,8 @@ namespace fasn {
 // mask_vec). MODE_GENERAL_SLOW: anything else (fp32 or unaligned bias, strided mask) through per-element loads.
 // The vector kernels are specialised at compile time on which operands exist (MODE_GENERAL_B / _M / _BM), so that every
 // load in the tile loop is unconditional and hipcc can emit counted s_waitcnt vmcnt(N) instead of draining the queue.
-enum { MODE_PLAIN = 0, MODE_CAUSAL = 1, MODE_GENERAL = 2 /* = bias + mask */, MODE_GENERAL_SLOW = 3, MODE_GENERAL_B = 4, MODE_GENERAL_M = 5 };
+enum { MODE_PLAIN = 0, MODE_CAUSAL = 1, MODE_GENERAL = 2 /* = bias + mask */, MODE_GENERAL_SLOW = 3, MODE_GENERAL_B = 4, MODE_GENERAL_M = 5,
+       MODE_KEYPAD = 6 /* boolean mask that depends on (batch, head, key) only - key padding - and no bias */ };
 
 struct FwdParams {
     const char* q;
@@ -58,6 +59,7 @@ struct FwdParams {
     // split-K (SPLIT kernels, short query / long key "decode" shapes): the keys of one (b,h, query block) are divided over
     // nsplit workgroups of tps tiles each; every workgroup writes its un-normalised fp32 accumulator and (m, l) per row,
     // fasn_fwd_combine_kernel merges them. The sink (+n) belongs to split 0.
+    int keypad_fallback;   // MODE_KEYPAD launches: the general mode (vector or element-load) the same mask would otherwise take
     int nsplit, tps;
     float* part_o;   // [B*H][nsplit][Sq][D]
     float* part_ml;  // [B*H][nsplit][Sq][2]
@@ -110,6 +112,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     constexpr bool VBIAS = MODE == MODE_GENERAL || MODE == MODE_GENERAL_B;   // vector bias present (compile time)
     constexpr bool VMASK = MODE == MODE_GENERAL || MODE == MODE_GENERAL_M;   // vector mask present (compile time)
     constexpr bool KPERM = VEC;
+    // MODE_KEYPAD: the mask is one byte per key for the whole (b,h): each lane fetches the byte of key k0 + lane one tile ahead,
+    // a ballot turns the 64 bytes into a wave-uniform bit word; tiles with all keys visible run as plain tiles, tiles with none
+    // are skipped, only the boundary tiles start their hidden scores at -inf. Key-padded batches cost what unpadded ones do.
+    constexpr bool KP = MODE == MODE_KEYPAD;
     if (SPLIT) {
         int blk;
         block_to_work(blockIdx.x, p.B * p.H, p.nqblk * p.nsplit, bh, blk);
@@ -134,7 +140,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
     const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
 
-    const bool causal = (MODE == MODE_CAUSAL) || (GEN && p.causal);
+    const bool causal = (MODE == MODE_CAUSAL) || ((GEN || KP) && p.causal);
     const int coff = p.Sk - p.Sq;  // key j visible to row i iff j <= i + coff
 
     // ---- number of K/V tiles this workgroup walks
@@ -328,6 +334,13 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int wave_first_vis = qw0 + coff;                 // last visible key of the wave's first row
     const int wave_last_vis = qw0 + QB * 32 - 1 + coff;    // last visible key of the wave's last row
 
+    __amdgpu_buffer_rsrc_t kprs;
+    uint32_t kp_next = 0;
+    if (KP) {
+        kprs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.mask + (b * p.ms[0] + h * p.ms[1])), 0, (unsigned)p.Sk, 0x00020000);
+        kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, t_begin * KT, 0);   // keys past Sk read as hidden
+    }
+
     // one K/V tile; LSET = register set that receives the prefetch issued here, SSET = set written to LDS at the end
     auto tile_body = [&](const int t, auto LSET, auto SSET) {
         // RING 1: the loop is unrolled by two (even tile: LSET = set 0, odd tile: LSET = set 1), so the LDS buffer index is a
@@ -337,6 +350,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         if (RING == 2 && !VEC) stage_direct(t + 2, (t + 2) % 3);   // past-the-end tiles are out of range for the descriptor
         else if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
 
+        uint64_t kp_bits = ~0ull;
+        if (KP) {   // this tile's visibility word; the next tile's bytes go in flight (older than the K/V prefetch in the vmcnt queue)
+            kp_bits = __ballot(kp_next != 0);
+            kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
+        }
         // wave-uniform tile classification
         bool skip = false;       // no visible element for this wave
         bool need_mask = false;  // some element needs the element-wise path
@@ -345,6 +363,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             need_mask = (k0 + KT - 1) > wave_first_vis;
         }
         if (k0 + KT > p.Sk) need_mask = true;
+        if (KP && kp_bits == 0) skip = true;
         // short query blocks (decode shapes): a wave without rows only helps staging the tiles (QB = 1 kernels: the QB = 2
         // ones are only dispatched for Sq >= 256 and keep their register allocation)
         if ((QB == 1 || SPLIT) && qw0 >= p.Sq) skip = true;
@@ -403,6 +422,17 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             if (VMASK) v = (((mraw[qb][kb][r >> 2] | nomask) >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
                             sacc[qb][kb][r] = v;
                         }
+            } else if (KP && kp_bits != ~0ull) {   // boundary tile of a key-padding mask: hidden keys start at -inf
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const uint32_t w = (uint32_t)(kp_bits >> (32 * kb)) >> (4 * hi);   // bit (r&3) + 8(r>>2) = key of register r
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = ((w >> ((r & 3) + 8 * (r >> 2))) & 1u) ? 0.f : -INFINITY;
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) sacc[qb][kb][r] = v;
+                    }
+                }
             } else {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)

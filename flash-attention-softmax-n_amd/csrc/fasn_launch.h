@@ -88,6 +88,7 @@ int launch_fwd_ring_one(FwdParams p, hipStream_t s) {
 template <typename Tag, int D, int QB, int OCC, int RING = 1, int PRIO = 0>
 int launch_fwd_ring(const FwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_PLAIN) return launch_fwd_ring_one<Tag, D, QB, MODE_PLAIN, OCC, RING, PRIO>(p, s);
+    if (mode == MODE_KEYPAD) return launch_fwd_ring_one<Tag, D, QB, MODE_KEYPAD, OCC, RING, PRIO>(p, s);
     return launch_fwd_ring_one<Tag, D, QB, MODE_CAUSAL, OCC, RING, PRIO>(p, s);
 }
 
@@ -176,6 +177,10 @@ int launch_fwd_cfg(FwdParams p, int mode, hipStream_t s) {
         auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_PLAIN, OCC, NW, 0, 0, 0, RING>;
         set_smem_attr(kern, smem);
         hipLaunchKernelGGL(kern, grid, block, smem, s, p);
+    } else if (mode == MODE_KEYPAD) {
+        auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_KEYPAD, OCC, NW, 0, 0, 0, RING>;
+        set_smem_attr(kern, smem);
+        hipLaunchKernelGGL(kern, grid, block, smem, s, p);
     } else {
         auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_CAUSAL, OCC, NW, 0, 0, 0, RING>;
         set_smem_attr(kern, smem);
@@ -218,6 +223,7 @@ template <typename Tag, int D, int QB, int OCC>
 int launch_fwd_drop(const FwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_PLAIN) return launch_fwd_drop_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
     if (mode == MODE_CAUSAL) return launch_fwd_drop_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
+    if (mode == MODE_KEYPAD) return launch_fwd_drop_one<Tag, D, QB, MODE_KEYPAD, OCC>(p, s);
     if (mode == MODE_GENERAL || mode == MODE_GENERAL_B || mode == MODE_GENERAL_M) {
         if constexpr (D == 128) return launch_fwd_drop_gen<Tag, D, 2, 8, 2>(p, s);
         else return launch_fwd_drop_gen<Tag, D, D == 32 ? 1 : 2, 4, 0>(p, s);
@@ -230,6 +236,7 @@ int launch_fwd_mode(const FwdParams& p, int mode, hipStream_t s) {
     switch (mode) {
         case MODE_PLAIN: return launch_fwd_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
         case MODE_CAUSAL: return launch_fwd_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
+        case MODE_KEYPAD: return launch_fwd_one<Tag, D, QB, MODE_KEYPAD, OCC>(p, s);
         default: return -7;  // general (mask / bias) mode is dispatched explicitly by the per-D translation units
     }
 }

@@ -133,9 +133,36 @@ def _hf_attention(module: Module, query: torch.Tensor, key: torch.Tensor, value:
             mask = attention_mask
         else:
             bias = attention_mask[..., : key.shape[-2]]
+            keymask = _as_key_padding_mask(bias)
+            if keymask is not None:      # 0 / "minus infinity" padding mask: the kernels' key-padding path (no bias traffic)
+                mask, bias = keymask, None
     out = flash_attention_n(query, key, value, softmax_n_param=n, scale=scaling, dropout_p=dropout if module.training else 0.0,
                             attn_mask=mask, attn_bias=bias, is_causal=bool(kwargs.get("is_causal", False)) and query.shape[2] > 1)
     return out.transpose(1, 2).contiguous(), None
+
+
+_KEYMASK_CACHE = {"key": None, "value": None}
+
+
+def _as_key_padding_mask(additive: torch.Tensor) -> Optional[torch.Tensor]:
+    """HF models hand every attention layer the same additive mask, [B,1,1,S] with 0 for real tokens and a huge negative
+    number for padding. If `additive` is exactly that (row-broadcast, only 0 and values <= -1e4), return the equivalent boolean
+    key mask, else None. The check costs one device synchronisation, so its result is cached per mask tensor: one sync per
+    forward pass, not per layer."""
+    if additive.dim() != 4 or additive.shape[1] != 1:
+        return None
+    if additive.shape[-2] != 1:
+        if additive.stride(-2) != 0:      # a real [.., L, S] mask (e.g. causal): not a key-padding mask
+            return None
+        additive = additive[..., :1, :]   # expanded view of a row-broadcast mask
+    key = (additive.data_ptr(), tuple(additive.shape), additive._version, additive.dtype)
+    if _KEYMASK_CACHE["key"] == key:
+        return _KEYMASK_CACHE["value"]
+    visible = additive == 0
+    binary = bool((visible | (additive <= -1e4)).all().item())
+    value = visible if binary else None
+    _KEYMASK_CACHE["key"], _KEYMASK_CACHE["value"] = key, value
+    return value
 
 
 def register_hf_attention() -> bool:
