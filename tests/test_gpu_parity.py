@@ -723,3 +723,37 @@ def test_attn_bias_gradient(pkg, dev, D, kind, dtype):
     else:
         for got, want, nm in ((out, o, "out"), (q.grad, qc.grad, "dq"), (k.grad, kc.grad, "dk"), (bias.grad, bc.grad, "dbias")):
             _check(got, want, dtype, f"{kind}/{nm}")
+
+
+# ---------------------------------------------------------------- key-padding masks (MODE_KEYPAD)
+@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("pattern", ["tail", "random", "blocks", "none_visible_in_one_batch"])
+def test_key_masks_with_row_stride_zero(pkg, dev, pattern, causal, D):
+    """boolean masks that depend on (batch, head, key) only take the per-tile visibility-word path: hidden keys anywhere in the
+    sequence, whole hidden tiles (skipped), a batch element with no visible key at all, per-head masks, odd key counts"""
+    dtype = torch.bfloat16
+    B, H, L, S = 3, 2, 200, 331
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    gen = torch.Generator().manual_seed(21)
+    if pattern == "tail":
+        mask = synth.keypad_mask(B, S, device="cpu")
+    elif pattern == "random":
+        mask = torch.rand(B, H, 1, S, generator=gen) < 0.6          # per head as well
+    elif pattern == "blocks":
+        mask = torch.ones(B, 1, 1, S, dtype=torch.bool)
+        mask[0, ..., 64:192] = False                                  # two whole 64-key tiles hidden
+        mask[1, ..., :70] = False
+        mask[2, ..., 300:] = False
+    else:
+        mask = torch.ones(B, 1, 1, S, dtype=torch.bool)
+        mask[1] = False
+    mask = mask.to(dev)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, attn_mask=mask, is_causal=causal)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0, attn_mask=mask, is_causal=causal)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"{pattern}/{nm}")
+    if pattern == "none_visible_in_one_batch":
+        assert (out[1] == 0).all() and (k.grad[1] == 0).all() and (v.grad[1] == 0).all()
