@@ -6,7 +6,7 @@ Public surface = flash_attention_softmax_n/__init__.py:3-9 of the reference:
 Every function runs on device tensors through libfasn.so; importing the package without the built
 library raises ImportError (no silent fallback).
 """
-from . import _lib, dropout, surgery
+from . import _lib, dropout, statistics, surgery
 from .flash_attn import flash_attention_n, flash_attention_n_triton, slow_attention_n
 from .softmax import softmax_n
 

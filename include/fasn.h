@@ -141,6 +141,15 @@ int fasn_softmax_n_bwd(const void* y, const void* dy, void* dx, int64_t rows, in
                        int64_t y_row_stride, int64_t dy_row_stride, int64_t dx_row_stride,
                        int32_t dtype, fasn_stream_t stream);
 
+/*
+ * Raw power sums of every row of a [rows, cols] matrix in ONE pass (col stride 1, row stride in elements):
+ * sums[row][0..3] += sum x, sum x^2, sum x^3, sum x^4 (fp64; the caller zeroes `sums`). Replaces the repeated
+ * mean / subtract / pow passes of flash_attention_softmax_n/analysis/statistics.py:9-79 (variance, skewness, kurtosis of
+ * activations) for device tensors. dtype: FASN_DTYPE_F16 / BF16 / F32; rows <= 65535.
+ */
+int fasn_moments(const void* x, double* sums, int64_t rows, int64_t cols, int64_t row_stride, int32_t dtype,
+                 fasn_stream_t stream);
+
 /* Timing helper for bench.py: elapsed milliseconds between two events recorded on `stream`
  * around `iters` back-to-back forward launches (HIP events on the launch stream). */
 int fasn_time_fwd(const fasn_fwd_args* args, fasn_stream_t stream, int32_t warmup, int32_t iters,

@@ -4,6 +4,9 @@ Run in the build container only (the GPU box has no /root/reference):  python te
 The reference's modules are imported by file path (its package __init__ needs a GPU when triton is installed);
 nothing of the reference is copied — the fixtures hold inputs' seeds/indices and the reference's OUTPUTS.
 
+  g6_statistics.npz  the reference's analysis/statistics.py (variance, skewness, kurtosis over several `dim`s and the per-sample
+                   batch means) on counter-generated tensors, one of them with heavy outliers.
+
 Fixtures:
   g1_c1.npz        BASELINE config 1 (2,2,128,32): explicit fp32 inputs (exactly representable in bf16 AND fp16) and the
                    reference slow_attention_n O, dQ, dK, dV for n in {0,0.5,1,4} x causal in {F,T}; its native-bf16 outputs;
@@ -158,8 +161,36 @@ def g5(cfg, S_override=None):
          checksums=np.array([synth.checksum(q), synth.checksum(k), synth.checksum(v), synth.checksum(do)], dtype=np.int64))
 
 
+def g6():
+    spec_s = importlib.util.spec_from_file_location("ref_statistics", "/root/reference/flash_attention_softmax_n/analysis/statistics.py")
+    st = importlib.util.module_from_spec(spec_s)
+    spec_s.loader.exec_module(st)
+    out = {}
+    for name, shape, seed, outl in (("a", (4, 37, 19), 41, False), ("b", (3, 5, 64, 33), 42, True)):
+        x = synth.counter_normal(shape, seed, std=1.5, dtype=torch.float32) + 0.3
+        if outl:                       # heavy tails: a few large entries, as outlier activations have
+            x.view(-1)[::97] *= 25.0
+        out[f"{name}_shape"] = np.array(shape)
+        out[f"{name}_seed"] = np.array(seed)
+        out[f"{name}_outliers"] = np.array(int(outl))
+        out[f"{name}_checksum"] = np.array(synth.checksum(x))
+        xd = x.double()
+        for dim_name, dim in (("all", None), ("last", -1), ("sample", tuple(range(1, x.ndim))), ("first", 0)):
+            out[f"{name}_var_{dim_name}"] = st.variance(xd, dim=dim).numpy()
+            out[f"{name}_skew_{dim_name}"] = st.skewness(xd, dim=dim).numpy()
+            out[f"{name}_kurt_{dim_name}"] = st.kurtosis(xd, dim=dim).numpy()
+            out[f"{name}_m3_{dim_name}"] = st.central_moment(xd, 3, dim=dim).numpy()
+        out[f"{name}_var_bm"] = np.array(st.variance_batch_mean(xd))
+        out[f"{name}_skew_bm"] = np.array(st.skewness_batch_mean(xd))
+        out[f"{name}_kurt_bm"] = np.array(st.kurtosis_batch_mean(xd))
+    save("g6_statistics.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if sys.argv[1:] == ["g6"]:
+        g6()
+        sys.exit(0)
     g1()
     g3()
     for c in CONFIGS:
@@ -167,3 +198,4 @@ if __name__ == "__main__":
     for c in ("c2", "c3", "m0"):
         g5(c)
     g5("c4", S_override=2048)
+    g6()
