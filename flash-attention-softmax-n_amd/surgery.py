@@ -9,8 +9,9 @@ module to keep in the model (the same object, modified in place, or a new one) o
 Built-in policy: Hugging Face self-attention modules that dispatch through `transformers.AttentionInterface`
 (transformers >= 4.48; BERT / RoBERTa here). The reference re-implements `BertSelfAttention.forward` around its eager
 `softmax_n` (surgery_functions/_bert.py:24-121, pinned to transformers < 4.33); here the module keeps its own forward and its
-attention function becomes `flash_attention_n` — fused, no [B,H,L,S] score tensor. XLNet's relative attention
-(surgery_functions/_xlnet.py) is not covered.
+attention function becomes `flash_attention_n` — fused, no [B,H,L,S] score tensor. XLNet (surgery_functions/_xlnet.py:25-75
+re-implements `rel_attn_core` around the eager softmax_n): here `rel_attn_core` keeps computing the position and segment
+scores, which become the `attn_bias` of one fused `flash_attention_n` call for content score, softmax_n, dropout and PV.
 """
 from __future__ import annotations
 
@@ -185,6 +186,12 @@ def register_hf_attention() -> bool:
     classes = [c for c in classes if c not in policy_registry]
     if classes:
         policy_registry.register(*classes)(hf_self_attention_surgery)
+    try:
+        from transformers.models.xlnet.modeling_xlnet import XLNetRelativeAttention
+        if XLNetRelativeAttention not in policy_registry:
+            policy_registry.register(XLNetRelativeAttention)(xlnet_relative_attention_surgery)
+    except Exception:
+        pass
     return True
 
 
@@ -197,4 +204,50 @@ def hf_self_attention_surgery(module: Module, module_index: int, softmax_n_param
         return None
     module.softmax_n_param = float(softmax_n_param)
     config._attn_implementation = HF_ATTENTION_NAME   # the config object is shared by all layers of the model
+    return module
+
+
+# ------------------------------------------------------------------------------------------------------------ XLNet
+def _xlnet_rel_attn_core(self, q_head, k_head_h, v_head_h, k_head_r, seg_mat=None, attn_mask=None, output_attentions=False):
+    """Replacement for `XLNetRelativeAttention.rel_attn_core` (same arguments and return value; tensors are [len, batch,
+    head, dim]). Position (bd) and segment (ef) scores are computed as the module always did and enter one fused
+    `flash_attention_n` call as the additive bias; the content score, softmax_n, dropout and the weighted sum happen in the
+    kernel. With `output_attentions=True` the probabilities must be returned, so that case takes the module's own einsum
+    route with the softmax_n row kernel."""
+    from .flash_attn import flash_attention_n
+    from .softmax import softmax_n
+    n = float(getattr(self, "softmax_n_param", 0.0))
+    bd = torch.einsum("ibnd,jbnd->bnij", q_head + self.r_r_bias, k_head_r)
+    bd = self.rel_shift_bnij(bd, klen=k_head_h.shape[0])
+    if seg_mat is None:
+        extra = bd
+    else:
+        ef = torch.einsum("ibnd,snd->ibns", q_head + self.r_s_bias, self.seg_embed)
+        extra = bd + torch.einsum("ijbs,ibns->bnij", seg_mat, ef)
+    visible = None
+    if attn_mask is not None:          # [i, j, b, n] (n may be 1), 1 = masked
+        visible = torch.einsum("ijbn->bnij", attn_mask) == 0
+    if output_attentions:
+        ac = torch.einsum("ibnd,jbnd->bnij", q_head + self.r_w_bias, k_head_h)
+        score = (ac + extra) * self.scale
+        if visible is not None:
+            score = score.masked_fill(~visible, float("-inf"))
+        prob = self.dropout(softmax_n(score, n=n, dim=3))
+        return torch.einsum("bnij,jbnd->ibnd", prob, v_head_h), torch.einsum("bnij->ijbn", prob)
+    q = (q_head + self.r_w_bias).permute(1, 2, 0, 3)      # [b, n, i, d]
+    k = k_head_h.permute(1, 2, 0, 3)
+    v = v_head_h.permute(1, 2, 0, 3)
+    out = flash_attention_n(q, k, v, softmax_n_param=n, scale=self.scale, attn_bias=extra * self.scale, attn_mask=visible,
+                            dropout_p=self.dropout.p if self.training else 0.0)
+    return out.permute(2, 0, 1, 3)                          # [i, b, n, d]
+
+
+def xlnet_relative_attention_surgery(module: Module, module_index: int, softmax_n_param: float) -> Optional[Module]:
+    """Built-in policy for `transformers` XLNetRelativeAttention (reference surgery_functions/_xlnet.py:11-22)."""
+    from types import MethodType
+    del module_index
+    if not hasattr(module, "rel_attn_core") or not hasattr(module, "rel_shift_bnij"):
+        return None
+    module.softmax_n_param = float(softmax_n_param)
+    module.rel_attn_core = MethodType(_xlnet_rel_attn_core, module)
     return module

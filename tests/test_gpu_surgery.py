@@ -67,3 +67,57 @@ def test_bert_with_softmax_n_attention(pkg, dev, n, dtype):
     (out.float() * valid).pow(2).sum().backward()   # sum, not mean: fp16 gradients of a mean underflow
     g = model.encoder.layer[0].attention.self.query.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
+
+
+def _xlnet_core_with_oracle_softmax_n(self, q_head, k_head_h, v_head_h, k_head_r, seg_mat=None, attn_mask=None, output_attentions=False):
+    """the module's own einsum formulation in fp32 with the oracle's softmax_n (what the reference's patched XLNet computes)"""
+    n = float(getattr(self, "softmax_n_param", 0.0))
+    f = lambda t: t.float()
+    ac = torch.einsum("ibnd,jbnd->bnij", f(q_head + self.r_w_bias), f(k_head_h))
+    bd = torch.einsum("ibnd,jbnd->bnij", f(q_head + self.r_r_bias), f(k_head_r))
+    bd = self.rel_shift_bnij(bd, klen=ac.shape[3])
+    ef = 0
+    if seg_mat is not None:
+        ef = torch.einsum("ibns,ijbs->bnij", torch.einsum("ibnd,snd->ibns", f(q_head + self.r_s_bias), f(self.seg_embed)), f(seg_mat))
+    score = (ac + bd + ef) * self.scale
+    if attn_mask is not None:
+        score = score.masked_fill(torch.einsum("ijbn->bnij", attn_mask) != 0, float("-inf"))
+    prob = ref_softmax_n(score, n=n)
+    return torch.einsum("bnij,jbnd->ibnd", prob, f(v_head_h)).to(q_head.dtype)
+
+
+@pytest.mark.parametrize("n", [0.0, 1.5])
+def test_xlnet_with_softmax_n_attention(pkg, dev, n):
+    from types import MethodType
+    from transformers import XLNetConfig, XLNetModel
+    from flash_attention_softmax_n_amd import surgery
+    if not surgery.register_hf_attention():
+        pytest.skip("transformers without AttentionInterface")
+    dtype = torch.float16
+    torch.manual_seed(0)
+    cfg = XLNetConfig(vocab_size=100, d_model=128, n_layer=2, n_head=2, d_inner=256, dropout=0.0)
+    model = XLNetModel(cfg).to(dev).to(dtype).eval()
+    ids = torch.randint(0, 100, (3, 96), device=dev)
+    att = torch.ones(3, 96, device=dev)
+    att[1, 60:] = 0
+    seg = torch.zeros(3, 96, dtype=torch.long, device=dev)
+    seg[:, 40:] = 1
+    layers = [m for m in model.modules() if type(m).__name__ == "XLNetRelativeAttention"]
+    for m in layers:       # expected: same weights, the module's einsum route with the oracle's softmax_n
+        m.softmax_n_param = n
+        m.rel_attn_core = MethodType(_xlnet_core_with_oracle_softmax_n, m)
+    with torch.no_grad():
+        want = model(input_ids=ids, attention_mask=att, token_type_ids=seg).last_hidden_state.float()
+    for m in layers:
+        del m.rel_attn_core
+    assert surgery.apply_attention_softmax_n(model, softmax_n_param=n) == cfg.n_layer
+    with torch.no_grad():
+        got = model(input_ids=ids, attention_mask=att, token_type_ids=seg).last_hidden_state.float()
+        got_p = model(input_ids=ids, attention_mask=att, token_type_ids=seg, output_attentions=True)
+    assert torch.isfinite(got).all()
+    valid = att.bool().unsqueeze(-1)
+    ulp = 2.0 ** -10 * want.abs().max().item()
+    err = ((got - want) * valid).abs().max().item()
+    assert err <= 3 * ulp, f"max-abs {err:.3e} (3 ulp = {3 * ulp:.3e})"
+    err_p = ((got_p.last_hidden_state.float() - want) * valid).abs().max().item()
+    assert err_p <= 3 * ulp and got_p.attentions is not None

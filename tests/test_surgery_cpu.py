@@ -145,3 +145,5 @@ def test_hf_policy_registration_is_idempotent(clean_registry):
     from transformers.models.bert.modeling_bert import BertSelfAttention
     assert surgery.HF_ATTENTION_NAME in AttentionInterface._global_mapping
     assert policy_registry[BertSelfAttention] is surgery.hf_self_attention_surgery
+    from transformers.models.xlnet.modeling_xlnet import XLNetRelativeAttention
+    assert policy_registry[XLNetRelativeAttention] is surgery.xlnet_relative_attention_surgery
