@@ -35,6 +35,7 @@ class FwdArgs(Structure):
         ("B", c_int32), ("H", c_int32), ("Sq", c_int32), ("Sk", c_int32), ("D", c_int32), ("Dv", c_int32),
         ("scale", c_float), ("softmax_n", c_float), ("causal", c_int32), ("dropout_p", c_float),
         ("seed", c_uint64), ("offset", c_uint64),
+        ("kv_group", c_int32),
     ]
 
 

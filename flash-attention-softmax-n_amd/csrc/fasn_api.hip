@@ -80,6 +80,8 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     p.bias_vec = 0;
     p.mask_vec = 0;
     p.keypad_fallback = 0;
+    if (a->kv_group < 0 || (a->kv_group > 1 && a->H % a->kv_group != 0)) return FASN_EINVAL;
+    p.kvg = a->kv_group > 1 ? a->kv_group : 1;
     p.batch_inner = 0;
     if (a->bias.ptr) {
         const int esz = p.bias_f32 ? 4 : 2;

@@ -154,8 +154,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     const int coff = p.Sk - p.Sq;
 
     const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
-    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
-    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
+    const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2;
     const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2;
 
     int ntiles = (p.Sk + KT - 1) / KT;
@@ -529,8 +529,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     const int coff = p.Sk - p.Sq;
 
     const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
-    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
-    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
+    const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2;
     const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2;
     const float* lsebase = p.lse + (int64_t)bh * p.Sq;
     const float* dltbase = bp.delta + (int64_t)bh * p.Sq;

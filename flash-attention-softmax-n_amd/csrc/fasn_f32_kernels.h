@@ -102,8 +102,8 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
     GenElem ge;
     if (GEN) ge.init(p, b, h);
     const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 4;
-    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 4;
-    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 4;
+    const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 4;
+    const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 4;
     int ntiles = (p.Sk + 63) / 64;
     if (causal) {
         const int kmax = min(q0 + BM, p.Sq) - 1 + coff;
@@ -264,8 +264,8 @@ __global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
     const int q0 = qblk * BM, qw0 = q0 + wave * 32, row = qw0 + l31, coff = p.Sk - p.Sq;
     GenElem ge;
     if (GEN) ge.init(p, b, h);
-    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 4;
-    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 4;
+    const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 4;
+    const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 4;
     int ntiles = (p.Sk + 63) / 64;
     if (causal) {
         const int kmax = min(q0 + BM, p.Sq) - 1 + coff;
@@ -412,8 +412,8 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
     for (int c = 0; c < KC; ++c) {
         kf[c] = vf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ok) {
-            kf[c] = *reinterpret_cast<const f32x4*>(p.k + (b * p.ks[0] + h * p.ks[1] + (int64_t)key * p.ks[2]) * 4 + (2 * c + hi) * 16);
-            vf[c] = *reinterpret_cast<const f32x4*>(p.v + (b * p.vs[0] + h * p.vs[1] + (int64_t)key * p.vs[2]) * 4 + (2 * c + hi) * 16);
+            kf[c] = *reinterpret_cast<const f32x4*>(p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1] + (int64_t)key * p.ks[2]) * 4 + (2 * c + hi) * 16);
+            vf[c] = *reinterpret_cast<const f32x4*>(p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1] + (int64_t)key * p.vs[2]) * 4 + (2 * c + hi) * 16);
         }
     }
     f32x16 dkacc[DB], dvacc[DB];

@@ -59,6 +59,7 @@ struct FwdParams {
     // split-K (SPLIT kernels, short query / long key "decode" shapes): the keys of one (b,h, query block) are divided over
     // nsplit workgroups of tps tiles each; every workgroup writes its un-normalised fp32 accumulator and (m, l) per row,
     // fasn_fwd_combine_kernel merges them. The sink (+n) belongs to split 0.
+    int kvg;        // query heads per K/V head (grouped-query attention); 1 = one K/V head per query head
     int keypad_fallback;   // MODE_KEYPAD launches: the general mode (vector or element-load) the same mask would otherwise take
     int nsplit, tps;
     float* part_o;   // [B*H][nsplit][Sq][D]
@@ -137,8 +138,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int qw0 = q0 + wave * (QB * 32);  // first row of this wave
 
     const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
-    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
-    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
+    const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2;
 
     const bool causal = (MODE == MODE_CAUSAL) || ((GEN || KP) && p.causal);
     const int coff = p.Sk - p.Sq;  // key j visible to row i iff j <= i + coff

@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(512, OCC) fasn_fwd_pp_kernel(const FwdParams p
     const int qw0 = q0 + wave * 32;
 
     const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
-    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
-    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
+    const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2;
     const int coff = p.Sk - p.Sq;
 
     int ntiles = (p.Sk + KT - 1) / KT;

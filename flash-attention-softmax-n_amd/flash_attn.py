@@ -66,6 +66,7 @@ def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal, dropout
     a.B, a.H, a.Sq, a.D = q.shape
     a.Sk = k.shape[2]
     a.Dv = v.shape[3]
+    a.kv_group = q.shape[1] // k.shape[1] if k.shape[1] != q.shape[1] else 0   # grouped-query attention: fewer K/V heads
     a.scale = scale
     a.softmax_n = n
     a.causal = 1 if causal else 0
@@ -124,6 +125,10 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
             _lib.check(lib.fasn_bwd(a, _stream_ptr(q.device)), "fasn_bwd")
         if dbias is not None and dbias.dtype != bias.dtype:
             dbias = dbias.to(bias.dtype)
+        Hkv = k.shape[1]
+        if Hkv != H:   # grouped-query attention: the kernels write per-query-head gradients, each K/V head gets its group's sum
+            dk = dk.view(B, Hkv, H // Hkv, S, D).sum(2, dtype=torch.float32).to(dk.dtype)
+            dv = dv.view(B, Hkv, H // Hkv, S, dv.shape[3]).sum(2, dtype=torch.float32).to(dv.dtype)
         return dq, dk, dv, None, dbias, None, None, None, None, None
 
 
@@ -157,8 +162,15 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
     S, Ev = key.shape[2], value.shape[3]
     if key.shape[3] != E or value.shape[2] != S:
         raise ValueError("key must be [B,H,S,E] and value [B,H,S,Ev]")
-    key = key.expand(B, H, S, E)
-    value = value.expand(B, H, S, Ev)
+    Hkv = key.shape[1]
+    if Hkv not in (1, H) and (H % Hkv != 0 or value.shape[1] != Hkv):
+        raise ValueError(f"key/value have {Hkv} heads: must be 1, {H}, or a divisor of {H} (grouped-query attention)")
+    if Hkv in (1, H):
+        key = key.expand(B, H, S, E)
+        value = value.expand(B, H, S, Ev)
+    else:   # grouped-query attention: query head h reads K/V head h // (H // Hkv), through the head stride (no copy)
+        key = key.expand(B, Hkv, S, E)
+        value = value.expand(B, Hkv, S, Ev)
 
     scale = (1.0 / sqrt(E)) if scale is None else float(scale)
     if scale < 0:  # exp2 folding assumes scale >= 0: move the sign into q

@@ -86,6 +86,9 @@ typedef struct fasn_fwd_args {
     float dropout_p;    /* in [0,1): attention-weight dropout; realised as thr/256 with thr = round(256 p) in [1,255] */
     uint64_t seed, offset; /* dropout stream: the keep bit of (b,h,row,key) is a pure function of (seed, offset, indices);
                               pass the SAME values to fasn_bwd (see flash-attention-softmax-n_amd/dropout.py) */
+    int32_t kv_group;      /* grouped-query attention (ABI 2): query head h reads K/V head h / kv_group, i.e. k and v are
+                              [B, H / kv_group, Sk, D] addressed through their head stride; 0 or 1 = one K/V head per query
+                              head. fasn_bwd still writes dk / dv per QUERY head [B,H,Sk,D]; the caller sums each group. */
 } fasn_fwd_args;
 
 /*

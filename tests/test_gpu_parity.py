@@ -760,3 +760,36 @@ def test_key_masks_with_row_stride_zero(pkg, dev, pattern, causal, D):
         _check(got, want, dtype, f"{pattern}/{nm}")
     if pattern == "none_visible_in_one_batch":
         assert (out[1] == 0).all() and (k.grad[1] == 0).all() and (v.grad[1] == 0).all()
+
+
+# ---------------------------------------------------------------- grouped-query attention (fewer K/V heads than query heads)
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("kind", ["plain", "causal+keypad", "bias", "decode"])
+def test_grouped_query_attention(pkg, dev, kind, D):
+    """K/V with H/G heads: query head h reads K/V head h // G through the head stride (generalises the reference's 3-D shared
+    K/V, flash_attn.py:75-79); the oracle sees the K/V heads repeated; dK/dV are the sums over each group"""
+    dtype = torch.bfloat16
+    B, H, Hkv = 2, 8, 2
+    L, S = (1, 4096) if kind == "decode" else (200, 264)
+    q = _rand((B, H, L, D), dtype, dev, 1).requires_grad_()
+    k = _rand((B, Hkv, S, D), dtype, dev, 2).requires_grad_()
+    v = _rand((B, Hkv, S, D), dtype, dev, 3).requires_grad_()
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    mask = bias = None
+    causal = kind == "causal+keypad"
+    if causal:
+        mask = synth.keypad_mask(B, S, device=dev)
+    if kind == "bias":
+        bias = torch.randn(H, L, S, generator=torch.Generator().manual_seed(2)).to(dtype).to(dev)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, is_causal=causal, attn_mask=mask, attn_bias=bias)
+    out.backward(do)
+    assert k.grad.shape == k.shape and v.grad.shape == v.shape
+    qc, kc, vc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v))
+    G = H // Hkv
+    o = ref_attention_n(qc, kc.repeat_interleave(G, dim=1), vc.repeat_interleave(G, dim=1), softmax_n_param=1.0, is_causal=causal,
+                        attn_mask=None if mask is None else mask.cpu(), attn_bias=None if bias is None else bias.float().cpu())
+    o.backward(do.cpu().float())
+    for got, want, nm in ((out, o, "out"), (q.grad, qc.grad, "dq"), (k.grad, kc.grad, "dk"), (v.grad, vc.grad, "dv")):
+        _check(got, want, dtype, f"gqa {kind} {nm}")
+    with pytest.raises(ValueError):
+        pkg.flash_attention_n(q, k[:, :1].expand(B, 3, S, D), v[:, :1].expand(B, 3, S, D))
