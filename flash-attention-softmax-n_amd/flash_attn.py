@@ -203,6 +203,22 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
         # one 63-bit seed per call from torch's CPU generator (honours torch.manual_seed); the kernels derive every
         # keep/drop bit from (seed, b, h, row, key) — see dropout.py for the host mirror
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    Hkv = k.shape[1]
+    if L == 1 and Hkv != H and dropout_p == 0.0:
+        # grouped-query decode: the G query heads of a group become G query ROWS of one problem per K/V head, so each K/V head
+        # is streamed once instead of G times. With one query position a row sees every key, so causal needs no flag, and a
+        # [B,H,1,S] mask / bias is a per-row mask / bias of the regrouped problem. All of it is views.
+        G = H // Hkv
+        try:
+            mask_g = None if mask is None else mask.view(B, Hkv, G, S)
+            bias_g = None if bias is None else bias.view(B, Hkv, G, S)
+        except RuntimeError:      # strides that cannot be regrouped without a copy: keep the per-head launch
+            mask_g = bias_g = False
+        if mask_g is not False:
+            out = _FlashAttentionSoftmaxN.apply(q.view(B, Hkv, G, dpad), k, v, mask_g, bias_g, n, scale, False, 0.0, 0)
+            out = out.view(B, H, 1, dpad)
+            _attention.last_seed = 0
+            return out if Ev == dpad else out[..., :Ev]
     out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, seed)
     _attention.last_seed = seed
     return out if Ev == dpad else out[..., :Ev]
