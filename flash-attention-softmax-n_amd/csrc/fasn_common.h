@@ -40,6 +40,13 @@ struct ET<bf16_tag> {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
     static FASN_DEV vec8 cvt8(f32x8 x) { return __builtin_convertvector(x, bf16x8); }
+    // acc + lo + hi of one packed pair (v_dot2c_f32_bf16 against {1, 1}): a row sum costs one VALU issue per TWO weights
+    static FASN_DEV float pair_sum(uint32_t pk, float acc) {
+        typedef __bf16 pr __attribute__((ext_vector_type(2)));
+        pr a;
+        __builtin_memcpy(&a, &pk, 4);
+        return __builtin_amdgcn_fdot2_f32_bf16(a, pr{(__bf16)1.0f, (__bf16)1.0f}, acc, false);
+    }
     static FASN_DEV vec4 cvt4(f32x4 x) { return __builtin_convertvector(x, bf16x4); }
     static FASN_DEV float to_f32(uint16_t bits) { return __uint_as_float(((uint32_t)bits) << 16); }
 };
@@ -52,6 +59,12 @@ struct ET<f16_tag> {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
     static FASN_DEV vec8 cvt8(f32x8 x) { return __builtin_convertvector(x, f16x8); }
+    static FASN_DEV float pair_sum(uint32_t pk, float acc) {
+        typedef _Float16 pr __attribute__((ext_vector_type(2)));
+        pr a;
+        __builtin_memcpy(&a, &pk, 4);
+        return __builtin_amdgcn_fdot2(a, pr{(_Float16)1.0f, (_Float16)1.0f}, acc, false);
+    }
     static FASN_DEV vec4 cvt4(f32x4 x) { return __builtin_convertvector(x, f16x4); }
     static FASN_DEV float to_f32(uint16_t bits) {
         _Float16 h;

@@ -24,6 +24,11 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.variant == 16) return launch_fwd_cfg<Tag, 128, 2, 1, 4, 1>(p, l.mode, s);   // 64 rows per wave, one wave per SIMD
     if (l.variant == 17) return launch_fwd_cfg<Tag, 128, 2, 1, 4, 0>(p, l.mode, s);
     if (l.variant == 18) return launch_fwd_cfg<Tag, 128, 2, 1, 4, 2>(p, l.mode, s);
+    if (l.variant == 80) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 1, 2>(p, l.mode, s);   // seeded accumulators + packed row sums
+    if (l.variant == 81) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 2, 2>(p, l.mode, s);
+    if (l.variant == 82) return launch_fwd_cfg<Tag, 128, 1, 2, 4, 0, 2>(p, l.mode, s);   // 4-wave kernels (small grids)
+    if (l.variant == 83) return launch_fwd_cfg<Tag, 128, 1, 2, 4, 2, 2>(p, l.mode, s);
+    if (l.variant == 84) return launch_fwd_cfg<Tag, 128, 1, 2, 4, 0, 0>(p, l.mode, s);   // = the small-grid default, for A/B
     if (l.variant == 4) return launch_fwd_pipe_mode<Tag, 128, 1, 2>(p, l.mode, s);      // software-pipelined, compiler order
     if (l.variant == 5) return launch_fwd_pipe_mode<Tag, 128, 1, 2, 1>(p, l.mode, s);   // + burst order
     if (l.variant == 6) return launch_fwd_pipe_mode<Tag, 128, 1, 1>(p, l.mode, s);
@@ -49,8 +54,10 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     // K/V tile, tiles loaded two ahead in two register sets) beats two 4-wave workgroups: 1134 vs 1014 TFLOP/s at
     // (4,32,8192,128) bf16, 886 vs 790 at (2,16,2048,128); staging + barrier cost 26 % of the 4-wave kernel at D = 128
     const long blocks256 = (long)((p.Sq + 255) / 256) * p.B * p.H;
-    if (l.variant == 0 && blocks256 >= 512 && p.Sq >= 256) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 1>(p, l.mode, s);
-    return launch_fwd_mode<Tag, 128, 1, 2>(p, l.mode, s);
+    // Both with seeded accumulators (Q pre-scaled, S starts at -m) and packed row sums: 1137 vs 1093 TFLOP/s at C4's shape,
+    // 680 vs 631 at (1,16,2048,128) where the 4-wave kernel with direct-to-LDS staging runs.
+    if (l.variant == 0 && blocks256 >= 512 && p.Sq >= 256) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 1, 2>(p, l.mode, s);
+    return launch_fwd_cfg<Tag, 128, 1, 2, 4, 2, 2>(p, l.mode, s);
 }
 int launch_fwd_d128(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     return l.dtype == 1 ? go<bf16_tag>(p, l, s) : go<f16_tag>(p, l, s);

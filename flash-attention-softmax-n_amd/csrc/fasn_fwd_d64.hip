@@ -22,11 +22,12 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     const bool gen = false;  // general modes returned above
     int v = l.variant;
     if (v == 0) {
-        // auto (what ABI callers get), measured on MI355X at (8,16,4096,64), 200 launches each:
-        //   plain : QB=2 / 2 waves per SIMD / two-set K/V ring  977 TFLOP/s  (single set 957, QB=1 / 3 waves 899-928)
-        //   causal: QB=1 / 3 waves per SIMD / ring             728 TFLOP/s  (QB=2 686: coarser diagonal, worse tail)
+        // auto (what ABI callers get), measured on MI355X at (8,16,4096,64), 200 launches each. All plain / causal / key-padding
+        // kernels run with seeded accumulators (Q pre-scaled, S starts at -m, row sums by v_dot2c on the packed weights):
+        //   plain : QB=2 / 2 waves per SIMD / direct-to-LDS  1058 TFLOP/s  (unseeded two-set ring 1005; QB=1 / 3 waves 983)
+        //   causal: QB=1 / 3 waves per SIMD / direct-to-LDS   772 TFLOP/s  (unseeded 734; QB=2 719: coarser diagonal, worse tail)
         const long blocks_qb2 = (long)((p.Sq + 255) / 256) * p.B * p.H;
-        v = ((l.mode == MODE_PLAIN || (l.mode == MODE_KEYPAD && !p.causal)) && blocks_qb2 >= 512 && p.Sq >= 256) ? 40 : 41;   // 512 = one full round of two workgroups per CU (C2: 791 vs 731 TFLOP/s)
+        v = ((l.mode == MODE_PLAIN || (l.mode == MODE_KEYPAD && !p.causal)) && blocks_qb2 >= 512 && p.Sq >= 256) ? 85 : 86;   // 512 = one full round of two workgroups per CU
     }
     switch (v) {
         // ---- production tuning points
@@ -48,6 +49,13 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 47: return launch_fwd_ring<Tag, 64, 2, 2, 1, 3>(p, l.mode, s);   // raised priority while issuing QK^T
         case 48: return launch_fwd_ring<Tag, 64, 1, 3, 1, 2>(p, l.mode, s);
         case 49: return launch_fwd_ring<Tag, 64, 1, 3, 1, 3>(p, l.mode, s);
+        // seeded accumulators (pre-scaled Q, S starts at -m); with the two-set ring the 16 extra registers per row block spill
+        case 82: return launch_fwd_ring<Tag, 64, 1, 2, 1, 0, 1>(p, l.mode, s);
+        case 83: return launch_fwd_ring<Tag, 64, 2, 2, 2, 0, 1>(p, l.mode, s);   // + direct-to-LDS staging (no staging registers)
+        case 84: return launch_fwd_ring<Tag, 64, 1, 3, 2, 0, 1>(p, l.mode, s);
+        case 85: return launch_fwd_ring<Tag, 64, 2, 2, 2, 0, 2>(p, l.mode, s);   // + row sums by v_dot2c on the packed weights
+        case 86: return launch_fwd_ring<Tag, 64, 1, 3, 2, 0, 2>(p, l.mode, s);
+        case 87: return launch_fwd_ring<Tag, 64, 1, 2, 1, 0, 2>(p, l.mode, s);
         case 50: return launch_fwd_split<Tag, 64, 2, 2>(p, l.mode, s);
         case 51: return launch_fwd_split<Tag, 64, 1, 3>(p, l.mode, s);
         case 52: return launch_fwd_split<Tag, 64, 1, 2>(p, l.mode, s);

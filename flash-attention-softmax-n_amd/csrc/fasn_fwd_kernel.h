@@ -80,11 +80,13 @@ constexpr float kSumLimit = 256.0f;
 // RING: 2 = no staging registers at all: `buffer_load_dwordx4 ... lds` moves each 16-byte chunk straight from HBM/L2 into
 // the LDS tile image (LDS address = wave base + 16*lane, so the swizzle is applied by choosing WHICH global chunk a lane
 // fetches), three LDS tile buffers, loads issued two tiles ahead, `s_waitcnt vmcnt` before the barrier that publishes a tile.
-template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0, int RING = 0, int SPLIT = 0>
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0, int RING = 0, int SPLIT = 0, int SEED = 0>
 __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
+    static_assert(!SEED || (MODE == MODE_PLAIN || MODE == MODE_CAUSAL || MODE == MODE_KEYPAD), "seeded accumulators: modes without an additive term");
     static_assert(!SPLIT || (RING != 1 && DROP == 0 && ABL == 0), "split-K: single-set or direct-to-LDS staging");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
+    constexpr bool PSUM = SEED >= 2 && !DROP;   // fast-path row sums from the packed weights
     constexpr int NT = NW * 64;
     constexpr int BM = NW * QB * 32;
     constexpr int ROWB = D * 2;
@@ -225,6 +227,14 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // ---- online-softmax state, per lane = per query row (log2 domain: y = x * log2(e))
     float m_run[QB], l_run[QB];
     f32x16 oacc[QB][DB];
+    // SEED: -m (0 while m is still -inf) in all 16 registers of an accumulator-shaped tuple = the C operand of the first QK^T MFMA
+    // of every key block; rewritten only when the exact path moves the max. `unseeded`: some row has no finite max yet.
+    f32x16 mseed[SEED ? QB : 1];
+    bool unseeded = !(p.n > 0.f && split == 0);
+#pragma unroll
+    for (int qb = 0; qb < (SEED ? QB : 1); ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mseed[qb][r] = 0.f;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const bool sink = p.n > 0.f && split == 0;
@@ -323,6 +333,21 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int s = 0; s < KS; ++s) retire_loads(qf[qb][s]);
+    // SEED: Q is multiplied by c = scale*log2e once, here (rounded to the operand type like core/flash_attn.py:81-83 rounds
+    // its pre-scaled q), and the QK^T accumulator starts at -m: the MFMAs deliver y - m and the per-score fma disappears.
+    if (SEED) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                uint16_t h[8];
+                __builtin_memcpy(h, &qf[qb][s], 16);
+                f32x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = E::to_f32(h[e]) * p.c;
+                qf[qb][s] = E::cvt8(f);
+            }
+    }
     // static priority for the second-dispatched half of an 8-wave workgroup (waves w and w+4 share a SIMD): the two
     // co-resident waves stop running their matrix / exponential phases in lock step
     if (PRIO && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(PRIO);
@@ -429,9 +454,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     const uint32_t w = (uint32_t)(kp_bits >> (32 * kb)) >> (4 * hi);   // bit (r&3) + 8(r>>2) = key of register r
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = ((w >> ((r & 3) + 8 * (r >> 2))) & 1u) ? 0.f : -INFINITY;
+                        const bool vis_r = ((w >> ((r & 3) + 8 * (r >> 2))) & 1u) != 0;
 #pragma unroll
-                        for (int qb = 0; qb < QB; ++qb) sacc[qb][kb][r] = v;
+                        for (int qb = 0; qb < QB; ++qb) sacc[qb][kb][r] = vis_r ? (SEED ? mseed[qb][r] : 0.f) : -INFINITY;
                     }
                 }
             } else {
@@ -440,7 +465,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = 0.f;
+                        for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = SEED ? mseed[qb][r] : 0.f;
             }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -485,7 +510,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             vec8 pf[QB][2][2];  // [qb][kb][t]: B operand of the PV MFMA
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                bool exact = need_mask;
+                bool exact = need_mask || (SEED && unseeded);
                 if (!exact) {
                     float rs = 0.f;
                     const float mneg = -m_run[qb];
@@ -504,16 +529,24 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                                 for (int e = 0; e < 8; e += 2) {
                                     const int r = 8 * t2 + e;
                                     const f32x2 s2 = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
-                                    const f32x2 t = __builtin_elementwise_fma(s2, c2, m2);
+                                    const f32x2 t = SEED ? s2 : __builtin_elementwise_fma(s2, c2, m2);
                                     f32x2 pv;
                                     if (ABL == 1) pv = s2;
                                     else pv = f32x2{fast_exp2(t[0]), fast_exp2(t[1])};
                                     x[e] = pv[0];
                                     x[e + 1] = pv[1];
-                                    rs2 += pv;
+                                    if (!PSUM) rs2 += pv;
                                 }
                                 if (DROP) drop8(x, qb, kb, t2);   // the row sum keeps the undropped weights
                                 pf[qb][kb][t2] = E::cvt8(x);
+                                if (PSUM) {   // row sum of the ROUNDED weights (what the PV MFMA multiplies), two per instruction
+                                    uint32_t w[4];
+                                    __builtin_memcpy(w, &pf[qb][kb][t2], 16);
+                                    rs2[0] = E::pair_sum(w[0], rs2[0]);
+                                    rs2[1] = E::pair_sum(w[1], rs2[1]);
+                                    rs2[0] = E::pair_sum(w[2], rs2[0]);
+                                    rs2[1] = E::pair_sum(w[3], rs2[1]);
+                                }
                             }
                         rs = rs2[0] + rs2[1];
                     };
@@ -535,7 +568,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             for (int r = 0; r < 16; ++r) {
                                 const int key = k0 + kb * 32 + (KPERM ? 16 * hi + r : (r & 3) + 8 * (r >> 2) + 4 * hi);
                                 const bool show = (key < p.Sk) && (key <= vis);
-                                const float y = show ? sacc[qb][kb][r] * p.c : -INFINITY;
+                                const float y = show ? (SEED ? sacc[qb][kb][r] : sacc[qb][kb][r] * p.c) : -INFINITY;   // SEED: already y - mref
                                 sacc[qb][kb][r] = y;
                                 mx = fmaxf(mx, y);
                             }
@@ -591,9 +624,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                         }
                     }
                     mx = max_across_halves(mx);
-                    const float m_new = fmaxf(m_run[qb], mx);
+                    const float mref = (SEED && m_run[qb] != -INFINITY) ? m_run[qb] : 0.f;   // SEED: what the scores are relative to
+                    const float m_new = fmaxf(m_run[qb], mx + mref);
                     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully hidden so far
                     const float alpha = fast_exp2(m_run[qb] - m_use);
+                    const float m_sub = m_use - mref;
                     float rs = 0.f;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
@@ -602,7 +637,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             f32x8 x;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                x[e] = fast_exp2(sacc[qb][kb][8 * t2 + e] - m_use);
+                                x[e] = fast_exp2(sacc[qb][kb][8 * t2 + e] - m_sub);
                                 rs += x[e];
                             }
                             if (DROP) drop8(x, qb, kb, t2);
@@ -610,6 +645,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                         }
                     l_run[qb] = l_run[qb] * alpha + rs;
                     m_run[qb] = m_new;
+                    if (SEED) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mseed[qb][r] = -m_use;
+                    }
                     if (!__all(alpha == 1.0f)) {
 #pragma unroll
                         for (int d = 0; d < DB; ++d)
@@ -618,7 +657,12 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     }
                 }
             }
-
+            if (SEED && unseeded) {   // rows that saw only hidden keys so far keep the wave on the exact path
+                bool u = false;
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) u |= (m_run[qb] == -INFINITY);
+                unseeded = __any(u);
+            }
 
             // ---- O^T += V^T P^T
 #pragma unroll

@@ -75,21 +75,21 @@ int launch_fwd_abl(FwdParams p, hipStream_t s) {
 }
 
 // plain / causal kernel with two staging register sets (K/V loaded two tiles ahead)
-template <typename Tag, int D, int QB, int MODE, int OCC, int RING = 1, int PRIO = 0>
+template <typename Tag, int D, int QB, int MODE, int OCC, int RING = 1, int PRIO = 0, int SEED = 0>
 int launch_fwd_ring_one(FwdParams p, hipStream_t s) {
     constexpr int BM = 4 * QB * 32;
     constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2;
     p.nqblk = (p.Sq + BM - 1) / BM;
-    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, 4, PRIO, 0, 0, RING>;
+    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, 4, PRIO, 0, 0, RING, 0, SEED>;
     if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
-template <typename Tag, int D, int QB, int OCC, int RING = 1, int PRIO = 0>
+template <typename Tag, int D, int QB, int OCC, int RING = 1, int PRIO = 0, int SEED = 0>
 int launch_fwd_ring(const FwdParams& p, int mode, hipStream_t s) {
-    if (mode == MODE_PLAIN) return launch_fwd_ring_one<Tag, D, QB, MODE_PLAIN, OCC, RING, PRIO>(p, s);
-    if (mode == MODE_KEYPAD) return launch_fwd_ring_one<Tag, D, QB, MODE_KEYPAD, OCC, RING, PRIO>(p, s);
-    return launch_fwd_ring_one<Tag, D, QB, MODE_CAUSAL, OCC, RING, PRIO>(p, s);
+    if (mode == MODE_PLAIN) return launch_fwd_ring_one<Tag, D, QB, MODE_PLAIN, OCC, RING, PRIO, SEED>(p, s);
+    if (mode == MODE_KEYPAD) return launch_fwd_ring_one<Tag, D, QB, MODE_KEYPAD, OCC, RING, PRIO, SEED>(p, s);
+    return launch_fwd_ring_one<Tag, D, QB, MODE_CAUSAL, OCC, RING, PRIO, SEED>(p, s);
 }
 
 // key-block-split kernel (fasn_fwd_split.h)
@@ -167,22 +167,22 @@ int launch_fwd_abl8(FwdParams p, hipStream_t s) {
 }
 
 // any (workgroup size, staging scheme) combination of the plain / causal kernel
-template <typename Tag, int D, int QB, int OCC, int NW, int RING>
+template <typename Tag, int D, int QB, int OCC, int NW, int RING, int SEED = 0>
 int launch_fwd_cfg(FwdParams p, int mode, hipStream_t s) {
     constexpr int BM = NW * QB * 32;
     constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2;
     p.nqblk = (p.Sq + BM - 1) / BM;
     const dim3 grid((unsigned)(p.nqblk * p.B * p.H)), block(NW * 64);
     if (mode == MODE_PLAIN) {
-        auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_PLAIN, OCC, NW, 0, 0, 0, RING>;
+        auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_PLAIN, OCC, NW, 0, 0, 0, RING, 0, SEED>;
         set_smem_attr(kern, smem);
         hipLaunchKernelGGL(kern, grid, block, smem, s, p);
     } else if (mode == MODE_KEYPAD) {
-        auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_KEYPAD, OCC, NW, 0, 0, 0, RING>;
+        auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_KEYPAD, OCC, NW, 0, 0, 0, RING, 0, SEED>;
         set_smem_attr(kern, smem);
         hipLaunchKernelGGL(kern, grid, block, smem, s, p);
     } else {
-        auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_CAUSAL, OCC, NW, 0, 0, 0, RING>;
+        auto kern = fasn_fwd_kernel<Tag, D, QB, MODE_CAUSAL, OCC, NW, 0, 0, 0, RING, 0, SEED>;
         set_smem_attr(kern, smem);
         hipLaunchKernelGGL(kern, grid, block, smem, s, p);
     }

@@ -520,7 +520,11 @@ def test_properties_at_full_size(pkg, dev, cfg):
         return o, lse
     o0, lse0 = fwd_lse(0.0)
     on, lsen = fwd_lse(1.0)
-    assert torch.allclose(torch.exp(lsen.double()), 1.0 + torch.exp(lse0.double()), rtol=1e-5)
+    # the row sum is taken over the weights AS ROUNDED for the PV product (2^-9 / 2^-12 relative each) and relative to a
+    # different running max in the two launches: the identity holds to one operand ulp per row and far better on average
+    rel = (torch.exp(lsen.double()) / (1.0 + torch.exp(lse0.double())) - 1.0).abs()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert rel.max().item() <= ulp and rel.mean().item() <= ulp / 16
     pred = o0.float() * torch.exp(lse0 - lsen).unsqueeze(-1)
     tol = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * o0.float().abs().max().item()
     assert (on.float() - pred).abs().max().item() <= tol
