@@ -123,7 +123,13 @@ struct TileDma {
 
 // ---------------------------------------------------------------------------------------------
 // dQ: workgroup = 4 waves x QB x 32 query rows, loop over 64-key tiles.
-template <typename Tag, int D, int QB, int MODE, int OCC, int DROP = 0>
+#ifndef FASN_DQ_SEED_D128
+#define FASN_DQ_SEED_D128 2
+#endif
+#ifndef FASN_DQ_SEED_D32
+#define FASN_DQ_SEED_D32 2
+#endif
+template <typename Tag, int D, int QB, int MODE, int OCC, int DROP = 0, int DQ_SEED = (D == 128 ? FASN_DQ_SEED_D128 : D == 32 ? FASN_DQ_SEED_D32 : 3)>
 __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams bp) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -234,6 +240,34 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         retire_loads(lse2[qb]);
         retire_loads(dlt[qb]);
     }
+    // Seeded accumulators (as in the forward): Q is multiplied by c = scale*log2e once, the S accumulator starts at -LSE*log2e
+    // and the dP accumulator at -delta, so the element pass is p = exp2(S'), dS = p * dP' - no fma, no subtraction. The seeds are
+    // accumulator-shaped splats (a lane owns one query row), constant for the whole kernel. Dropout scales dP before delta is
+    // subtracted, so those instantiations only seed S; the element-load kernels (MODE_GENERAL_SLOW) keep the unseeded arithmetic.
+    // Each splat costs 16 registers per query block: where the kernel is at its register limit only one (or none) is used
+    // (DQ_SEED: bit 0 = S, bit 1 = dP; the vector general mode builds its S start value per element and always seeds S).
+    constexpr bool SEED_S = MODE != MODE_GENERAL_SLOW && (MODE == MODE_GENERAL || (DQ_SEED & 1));
+    constexpr bool SEED_P = MODE != MODE_GENERAL_SLOW && !DROP && (DQ_SEED & 2);
+    f32x16 sseed[(SEED_S && MODE != MODE_GENERAL) ? QB : 1], dseed[SEED_P ? QB : 1];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        if (SEED_S) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                uint16_t hq[8];
+                __builtin_memcpy(hq, &qf[qb][s], 16);
+                f32x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hq[e]) * p.c;
+                qf[qb][s] = E::cvt8(f);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (SEED_S && MODE != MODE_GENERAL) sseed[qb][r] = -lse2[qb];
+            if (SEED_P) dseed[qb][r] = -dlt[qb];
+        }
+    }
 
     // MODE_GENERAL (vector path, same scheme as the forward): K/V rows staged in key-permuted order so a lane's 16
     // accumulator registers of a 32-key block are 16 consecutive keys; the wave's bias / mask image of each tile goes
@@ -244,7 +278,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     u32x4 brw, mrw;
     unsigned bvo[QB][4], mvo[QB][2];
     const uint32_t nomask = (VEC && p.mask == nullptr) ? 0x01010101u : 0u;
-    const float binv = VEC ? kLog2e / p.c : 0.f;
+    const float binv = VEC ? kLog2e : 0.f;   // Q is pre-scaled: S' = bias*log2e - LSE*log2e + q'.k
     char* const ldsGB = smem + 4 * TILEB + wave * (QB * 6144);
     char* const ldsGM = ldsGB + QB * 4096;
     const uint32_t ldsGB_a = lds_addr(ldsGB), ldsGM_a = lds_addr(ldsGM);
@@ -357,15 +391,15 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                     for (int r = 0; r < 16; ++r) {
                         if (VEC) {
                             const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
-                            const float v = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * binv;
+                            const float v = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), binv, -lse2[qb]);
                             sacc[qb][r] = ((mraw[qb][kb][r >> 2] >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
                         } else if (KP) {   // bit (r&3) + 8(r>>2) + 4hi of this 32-key block
                             const uint32_t w = (uint32_t)(kp_bits >> (32 * kb)) >> (4 * hi);
-                            sacc[qb][r] = ((w >> ((r & 3) + 8 * (r >> 2))) & 1u) ? 0.f : -INFINITY;
+                            sacc[qb][r] = ((w >> ((r & 3) + 8 * (r >> 2))) & 1u) ? (SEED_S ? sseed[qb][r] : 0.f) : -INFINITY;
                         } else {
-                            sacc[qb][r] = 0.f;
+                            sacc[qb][r] = SEED_S ? sseed[qb][r] : 0.f;
                         }
-                        pacc[qb][r] = 0.f;
+                        pacc[qb][r] = SEED_P ? dseed[qb][r] : 0.f;
                     }
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
@@ -404,7 +438,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                                     }
                                 }
                             }
-                            float pv = (MODE == MODE_GENERAL_SLOW) ? fast_exp2(y - lse2[qb]) : fast_exp2(__builtin_fmaf(sacc[qb][r], p.c, -lse2[qb]));
+                            float pv = (MODE == MODE_GENERAL_SLOW) ? fast_exp2(y - lse2[qb])
+                                       : SEED_S ? fast_exp2(sacc[qb][r]) : fast_exp2(__builtin_fmaf(sacc[qb][r], p.c, -lse2[qb]));
                             if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                             float dp = pacc[qb][r];
                             if (DROP) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
@@ -412,7 +447,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                                 const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)((k0 + kb * 32 + (VEC ? 16 * hi + 4 * (r >> 2) : 8 * (r >> 2) + 4 * hi)) >> 2));
                                 dp = drop_keep(hsh, r & 3, p.drop_thr) ? dp * p.drop_scale : 0.f;
                             }
-                            sacc[qb][r] = pv * (dp - dlt[qb]);
+                            sacc[qb][r] = SEED_P ? pv * dp : pv * (dp - dlt[qb]);
                         }
                     };
                     if (need_mask) elems(std::true_type{});
@@ -574,6 +609,11 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 dvacc[kb][d][r] = 0.f;
             }
 
+    // Seeded accumulators: K (held in registers, used for S only) is multiplied by c = scale*log2e once; the S accumulator of a
+    // query-row block starts at -LSE*log2e and the dP accumulator at -delta of the register's row (the 16 per-row values a lane
+    // reads from LDS anyway), so the element pass is p = exp2(S'), dS = p * dP'. Dropout scales dP first: those kernels seed S only.
+    constexpr bool SEED_S = MODE != MODE_GENERAL_SLOW;
+    constexpr bool SEED_P = SEED_S && !DROP;
     u32x4 stQ[NLD], stD[NLD];
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qbase), 0, bp.qbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dobase), 0, bp.dobytes, 0x00020000);
@@ -598,8 +638,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 l = lsebase[gr];
                 x = dltbase[gr];
             }
+            // seeded kernels keep the NEGATED statistics in LDS: they are the start values of the S / dP accumulators
             stL = (l == -INFINITY) ? INFINITY : l * kLog2e;
-            stX = x;
+            if (SEED_S) stL = -stL;
+            stX = SEED_P ? -x : x;
         }
     };
     auto stats_lstore = [&](int buf) {
@@ -643,7 +685,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     u32x4 stA[ACH];
     u32x2 stM[ACH];
     const uint32_t nomask = (VEC && p.mask == nullptr) ? 0x01010101u : 0u;
-    const float binv = VEC ? kLog2e / p.c : 0.f;
+    const float binv = VEC ? kLog2e : 0.f;   // K is pre-scaled: S' = add*log2e - LSE*log2e + q.k'
     const uint32_t ninf16 = std::is_same<Tag, bf16_tag>::value ? 0xFF80u : 0xFC00u;   // -inf in the 16-bit type
     if (VEC) {
         const char* bb = p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
@@ -687,6 +729,14 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         for (int s = 0; s < KS; ++s) {
             retire_loads(kf[kb][s]);
             retire_loads(vf[kb][s]);
+            if (SEED_S) {
+                uint16_t hk[8];
+                __builtin_memcpy(hk, &kf[kb][s], 16);
+                f32x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hk[e]) * p.c;
+                kf[kb][s] = E::cvt8(f);
+            }
         }
 
     constexpr bool KPD = MODE == MODE_KEYPAD;
@@ -735,6 +785,18 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         if (!skip) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
+                // per-row statistics for the 16 rows this lane's registers cover (negated where they seed the accumulators)
+                f32x16 lr, xr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 a = *LDS_PTR(const f32x4, tL + qb * 32 + 8 * g + 4 * hi);
+                    f32x4 c = *LDS_PTR(const f32x4, tX + qb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lr[4 * g + e] = a[e];
+                        xr[4 * g + e] = c[e];
+                    }
+                }
                 // S[q][key], dP[q][key] for 32 rows x KB*32 keys
                 f32x16 sacc[KB], pacc[KB];
 #pragma unroll
@@ -747,15 +809,17 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                             uint16_t ab[8];
                             __builtin_memcpy(ab, &av, 16);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) sacc[kb][8 * t2 + e] = E::to_f32(ab[e]) * binv;
+                            for (int e = 0; e < 8; ++e) sacc[kb][8 * t2 + e] = __builtin_fmaf(E::to_f32(ab[e]), binv, lr[8 * t2 + e]);
                         }
-                    } else {
-                        const float v0 = (KPD && !kp_keep[kb]) ? -INFINITY : 0.f;   // key-padding: a lane's key is hidden for every row
+                    } else if (KPD && !kp_keep[kb]) {   // key-padding: a lane's key is hidden for every row
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) sacc[kb][r] = v0;
+                        for (int r = 0; r < 16; ++r) sacc[kb][r] = -INFINITY;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[kb][r] = SEED_S ? lr[r] : 0.f;
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pacc[kb][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) pacc[kb][r] = SEED_P ? xr[r] : 0.f;
                 }
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
@@ -765,18 +829,6 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                     for (int kb = 0; kb < KB; ++kb) {
                         sacc[kb] = E::mfma(qa, kf[kb][s], sacc[kb]);
                         pacc[kb] = E::mfma(da, vf[kb][s], pacc[kb]);
-                    }
-                }
-                // per-row statistics for the 16 rows this lane's registers cover
-                float lr[16], xr[16];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 a = *LDS_PTR(const f32x4, tL + qb * 32 + 8 * g + 4 * hi);
-                    f32x4 c = *LDS_PTR(const f32x4, tX + qb * 32 + 8 * g + 4 * hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        lr[4 * g + e] = a[e];
-                        xr[4 * g + e] = c[e];
                     }
                 }
                 vec8 pfr[KB][2], dsfr[KB][2];
@@ -805,7 +857,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                                 }
                             }
                         }
-                        float pv = (MODE == MODE_GENERAL_SLOW) ? fast_exp2(y - lr[r]) : fast_exp2(__builtin_fmaf(sacc[kb][r], p.c, -lr[r]));
+                        float pv = (MODE == MODE_GENERAL_SLOW) ? fast_exp2(y - lr[r]) : fast_exp2(sacc[kb][r]);
                         if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                         float dp = pacc[kb][r];
                         float pd = pv;
@@ -818,7 +870,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                             pd = keep ? pv * p.drop_scale : 0.f;
                         }
                         sacc[kb][r] = pd;                     // dropped weights feed dV
-                        pacc[kb][r] = pv * (dp - xr[r]);      // dS uses the undropped P
+                        pacc[kb][r] = SEED_P ? pv * dp : pv * (dp - xr[r]);      // dS uses the undropped P
                     }
                     };
                     if (need_mask) elems(std::true_type{});
