@@ -3,10 +3,17 @@
 namespace fasn {
 template <typename Tag>
 static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (l.variant == 1) {   // A/B: unseeded
+        switch (l.mode) {
+            case MODE_GENERAL: case MODE_GENERAL_B: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2>(p, s);
+            case MODE_GENERAL_M: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_M, 2, 8, 2>(p, s);
+            default: break;
+        }
+    }
     switch (l.mode) {
-        case MODE_GENERAL: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2>(p, s);
-        case MODE_GENERAL_B: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2>(p, s);   // the bias-only instantiation spills (37 VGPRs) at D = 128
-        case MODE_GENERAL_M: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_M, 2, 8, 2>(p, s);
+        case MODE_GENERAL: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);
+        case MODE_GENERAL_B: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);   // the bias-only instantiation spills (37 VGPRs) at D = 128
+        case MODE_GENERAL_M: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_M, 2, 8, 2, 2>(p, s);
         default: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_SLOW, 1>(p, s);
     }
 }

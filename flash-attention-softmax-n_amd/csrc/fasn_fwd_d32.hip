@@ -4,9 +4,9 @@ namespace fasn {
 template <typename Tag>
 static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     switch (l.mode) {
-        case MODE_GENERAL: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, 1>(p, s);
-        case MODE_GENERAL_B: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_B, 1>(p, s);
-        case MODE_GENERAL_M: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_M, 1>(p, s);
+        case MODE_GENERAL: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, 1, 4, 0, 2>(p, s);
+        case MODE_GENERAL_B: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_B, 1, 4, 0, 2>(p, s);
+        case MODE_GENERAL_M: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_M, 1, 4, 0, 2>(p, s);
         default: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_SLOW, 1>(p, s);
     }
 }

@@ -8,10 +8,18 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.variant == 71) return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 8>(p, s);       // A/B: 8 waves
     if (l.variant == 72) return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 4, 2>(p, s);    // A/B: direct K/V staging
     if (l.variant == 73) return launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 2, 4, 2>(p, s);
+    if (l.variant == 1) {   // A/B: unseeded
+        switch (l.mode) {
+            case MODE_GENERAL: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2>(p, s);
+            case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_B, 2>(p, s);
+            case MODE_GENERAL_M: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_M, 2>(p, s);
+            default: break;
+        }
+    }
     switch (l.mode) {
-        case MODE_GENERAL: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2>(p, s);
-        case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_B, 2>(p, s);
-        case MODE_GENERAL_M: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_M, 2>(p, s);
+        case MODE_GENERAL: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 4, 0, 2>(p, s);
+        case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_B, 2, 4, 0, 2>(p, s);
+        case MODE_GENERAL_M: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_M, 2, 4, 0, 2>(p, s);
         default: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_SLOW, 1>(p, s);
     }
 }

@@ -82,7 +82,7 @@ constexpr float kSumLimit = 256.0f;
 // fetches), three LDS tile buffers, loads issued two tiles ahead, `s_waitcnt vmcnt` before the barrier that publishes a tile.
 template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0, int RING = 0, int SPLIT = 0, int SEED = 0>
 __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
-    static_assert(!SEED || (MODE == MODE_PLAIN || MODE == MODE_CAUSAL || MODE == MODE_KEYPAD), "seeded accumulators: modes without an additive term");
+    static_assert(!SEED || MODE != MODE_GENERAL_SLOW, "seeded accumulators: not for the element-load kernels");
     static_assert(!SPLIT || (RING != 1 && DROP == 0 && ABL == 0), "split-K: single-set or direct-to-LDS staging");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -229,10 +229,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     f32x16 oacc[QB][DB];
     // SEED: -m (0 while m is still -inf) in all 16 registers of an accumulator-shaped tuple = the C operand of the first QK^T MFMA
     // of every key block; rewritten only when the exact path moves the max. `unseeded`: some row has no finite max yet.
-    f32x16 mseed[SEED ? QB : 1];
+    f32x16 mseed[(SEED && !VEC) ? QB : 1];   // the vector general modes build their start values per element from -m
     bool unseeded = !(p.n > 0.f && split == 0);
 #pragma unroll
-    for (int qb = 0; qb < (SEED ? QB : 1); ++qb)
+    for (int qb = 0; qb < ((SEED && !VEC) ? QB : 1); ++qb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mseed[qb][r] = 0.f;
 #pragma unroll
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // MODE_GENERAL launched without a mask (bias only, where the bias-only instantiation is the worse kernel): every byte reads as set
     const uint32_t nomask = (VMASK && p.mask == nullptr) ? 0x01010101u : 0u;
     constexpr bool bias_fold = VBIAS;
-    const float binv = bias_fold ? kLog2e / p.c : 0.f;
+    const float binv = bias_fold ? (SEED ? kLog2e : kLog2e / p.c) : 0.f;   // SEED: Q is pre-scaled, S' = bias*log2e - m + q'.k
     if (RING == 2) {
         if (ntiles > t_begin) {
             if (VEC) gen_dma(t_begin);
@@ -435,19 +435,21 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 // S' starts from the additive term: bias*log2e/c where the mask byte is set, -inf where it is clear
                 // (S' = add + q.k, y = c*S'): from here on the tile is handled exactly like a plain one
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
+                for (int qb = 0; qb < QB; ++qb) {
+                    const float mneg = (SEED && m_run[qb] != -INFINITY) ? -m_run[qb] : 0.f;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            float v = 0.f;
+                            float v = mneg;
                             if (VBIAS) {
                                 const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
-                                v = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * binv;
+                                v = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), binv, mneg);
                             }
                             if (VMASK) v = (((mraw[qb][kb][r >> 2] | nomask) >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
                             sacc[qb][kb][r] = v;
                         }
+                }
             } else if (KP && kp_bits != ~0ull) {   // boundary tile of a key-padding mask: hidden keys start at -inf
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
@@ -645,7 +647,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                         }
                     l_run[qb] = l_run[qb] * alpha + rs;
                     m_run[qb] = m_new;
-                    if (SEED) {
+                    if (SEED && !VEC) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) mseed[qb][r] = -m_use;
                     }

@@ -27,13 +27,13 @@ inline void set_smem_attr(K kern, int smem) {
     if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
-template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int RING = 0>
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int RING = 0, int SEED = 0>
 int launch_fwd_one(FwdParams p, hipStream_t s) {
     constexpr int BM = NW * QB * 32;
     constexpr bool VEC = MODE == MODE_GENERAL || MODE == MODE_GENERAL_B || MODE == MODE_GENERAL_M;
     constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2 + (VEC ? NW * QB * 6144 : 0);   // + per-wave bias / mask images
     p.nqblk = (p.Sq + BM - 1) / BM;
-    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, 0, 0, 0, RING>;
+    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, 0, 0, 0, RING, 0, SEED>;
     if (smem > 48 * 1024) {
         static bool done = false;  // benign race: idempotent attribute
         if (!done) {
