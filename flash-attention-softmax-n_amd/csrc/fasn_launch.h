@@ -202,7 +202,8 @@ int launch_fwd_drop_one(FwdParams p, hipStream_t s) {
     constexpr int BM = 4 * QB * 32;
     constexpr int smem = 4 * KT * D * 2;
     p.nqblk = (p.Sq + BM - 1) / BM;
-    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, 4, 0, 0, 1>;
+    constexpr int SEED = MODE == MODE_GENERAL_SLOW ? 0 : 1;   // seeded S accumulators; row sums stay fp32 (taken before the drop)
+    auto kern = fasn_fwd_kernel<Tag, D, QB, MODE, OCC, 4, 0, 0, 1, 0, 0, SEED>;
     if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -6;
@@ -214,7 +215,7 @@ int launch_fwd_drop_gen(FwdParams p, hipStream_t s) {
     constexpr int BM = NW * 32;
     constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2 + NW * 6144;
     p.nqblk = (p.Sq + BM - 1) / BM;
-    auto kern = fasn_fwd_kernel<Tag, D, 1, MODE_GENERAL, OCC, NW, 0, 0, 1, RING>;
+    auto kern = fasn_fwd_kernel<Tag, D, 1, MODE_GENERAL, OCC, NW, 0, 0, 1, RING, 0, 1>;
     set_smem_attr(kern, smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(NW * 64), smem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -6;
