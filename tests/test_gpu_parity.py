@@ -736,9 +736,14 @@ def test_attn_bias_gradient(pkg, dev, D, kind, dtype):
 @pytest.mark.parametrize("D", [32, 64, 128])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("pattern", ["tail", "random", "blocks", "none_visible_in_one_batch"])
-def test_key_masks_with_row_stride_zero(pkg, dev, pattern, causal, D):
+@pytest.mark.parametrize("n", [1.0, 0.0])
+def test_key_masks_with_row_stride_zero(pkg, dev, n, pattern, causal, D):
     """boolean masks that depend on (batch, head, key) only take the per-tile visibility-word path: hidden keys anywhere in the
-    sequence, whole hidden tiles (skipped), a batch element with no visible key at all, per-head masks, odd key counts"""
+    sequence, whole hidden tiles (skipped), a batch element with no visible key at all, per-head masks, odd key counts.
+    n = 0: no sink column, so a row has no finite max until its first visible key (left padding: the first tiles are hidden) and
+    the seeded kernels must stay on the exact path until then"""
+    if n == 0.0 and pattern == "none_visible_in_one_batch":
+        pytest.skip("softmax_0 over an empty key set is 0/0 in the oracle")
     dtype = torch.bfloat16
     B, H, L, S = 3, 2, 200, 331
     q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
@@ -757,9 +762,9 @@ def test_key_masks_with_row_stride_zero(pkg, dev, pattern, causal, D):
         mask = torch.ones(B, 1, 1, S, dtype=torch.bool)
         mask[1] = False
     mask = mask.to(dev)
-    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, attn_mask=mask, is_causal=causal)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, attn_mask=mask, is_causal=causal)
     out.backward(do)
-    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0, attn_mask=mask, is_causal=causal)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=n, attn_mask=mask, is_causal=causal)
     for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
         _check(got, want, dtype, f"{pattern}/{nm}")
     if pattern == "none_visible_in_one_batch":
