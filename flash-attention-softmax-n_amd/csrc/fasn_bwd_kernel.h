@@ -207,9 +207,11 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     TileStage<D, NLD> tsK, tsV;
     tsK.init(tid, p.ks[2], MODE == MODE_GENERAL);
     tsV.init(tid, p.vs[2], MODE == MODE_GENERAL);
-    // D = 128: K/V tiles go straight to LDS. With staging registers the S / dP accumulators do not fit in the 256 VGPRs next to
-    // the Q and dO fragments, the compiler parks them in AGPRs and pays ~130 v_accvgpr moves per tile to use them.
-    constexpr bool DIRECT = D == 128 && MODE != MODE_GENERAL_SLOW;
+    // K/V tiles go straight to LDS (`buffer_load ... lds`, one tile ahead): no staging registers and no ds_write instructions.
+    // At D = 128 the S / dP accumulators would not fit next to staging registers (the compiler parks them in AGPRs and pays ~130
+    // v_accvgpr moves per tile); at D = 64 it is worth 2 % of the backward (same-box A/B 1.845 -> 1.78 ms with the dK/dV kernel).
+    // Only the element-load kernels (MODE_GENERAL_SLOW) keep the register-staged path.
+    constexpr bool DIRECT = MODE != MODE_GENERAL_SLOW;
     TileDma<D, NLD> tdK, tdV;
     const u32x4 krw = make_rsrc_words(kbase, p.kbytes), vrw = make_rsrc_words(vbase, p.vbytes);
     const uint32_t ldsK_w = lds_addr(ldsK) + wave * 1024, ldsV_w = lds_addr(ldsV) + wave * 1024;
@@ -620,8 +622,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     TileStage<D, NLD> tsQ, tsD;
     tsQ.init(tid, p.qs[2]);
     tsD.init(tid, bp.dos[2]);
-    // vector general mode: Q / dO tiles go straight to LDS (the staging registers are needed for the additive tile)
-    constexpr bool DIRECT = MODE == MODE_GENERAL || (D == 128 && MODE != MODE_GENERAL_SLOW);
+    // Q / dO tiles go straight to LDS (the vector general mode needs the staging registers for its additive tile; the plain
+    // modes save the ds_write instructions); the element-load kernels keep the register-staged path
+    constexpr bool DIRECT = MODE != MODE_GENERAL_SLOW;
     TileDma<D, NLD> tdQ, tdD;
     const u32x4 qrw = make_rsrc_words(qbase, bp.qbytes), drw = make_rsrc_words(dobase, bp.dobytes);
     const uint32_t ldsQ_w = lds_addr(smem) + wave * 1024, ldsDO_w = ldsQ_w + 2 * TILEB;
