@@ -141,6 +141,9 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     } else {
         l.mode = a->causal ? MODE_CAUSAL : MODE_PLAIN;
     }
+    // The vector kernels multiply Q (or K) by c = scale*log2e in the operand type before the MFMAs. In fp16 a large scale could
+    // push an otherwise representable operand past 65504 there: such calls take the element-load kernels, which scale in fp32.
+    if (a->dtype == FASN_DTYPE_F16 && fabsf(p.c) > 8.f) l.mode = MODE_GENERAL_SLOW;
     l.variant = internal_variant();
     p.nsplit = 1;
     p.tps = 0;

@@ -771,6 +771,31 @@ def test_key_masks_with_row_stride_zero(pkg, dev, n, pattern, causal, D):
         assert (out[1] == 0).all() and (k.grad[1] == 0).all() and (v.grad[1] == 0).all()
 
 
+# ---------------------------------------------------------------- fp16 operands that a pre-scaled Q / K could overflow
+@pytest.mark.parametrize("causal", [False, True])
+def test_fp16_large_scale_does_not_overflow_the_prescaled_operand(pkg, dev, causal):
+    """scale*log2e = 92 with |q| up to ~1000: q*c leaves the fp16 range although every score q.k*scale is moderate. Such calls
+    must not take the kernels that pre-scale Q / K in the operand type. Checked against the same problem with the magnitudes
+    moved from q to k by a power of two (identical products) and against the oracle evaluated in fp32."""
+    dtype = torch.float16
+    B, H, L, S, D = 1, 2, 160, 200, 64
+    q = (_rand((B, H, L, D), dtype, dev, 1).float() * 600).to(dtype).requires_grad_()
+    k = (_rand((B, H, S, D), dtype, dev, 2).float() * (2.0 ** -12)).to(dtype).requires_grad_()
+    v = _rand((B, H, S, D), dtype, dev, 3).requires_grad_()
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, scale=64.0, is_causal=causal)
+    out.backward(do)
+    for nm, t in (("out", out), ("dq", q.grad), ("dv", v.grad)):   # dK = scale * dS^T Q is legitimately beyond fp16 here
+        assert torch.isfinite(t).all(), nm
+    q2 = (q.detach().float() / 512).to(dtype).requires_grad_()
+    k2 = (k.detach().float() * 512).to(dtype).requires_grad_()
+    out2 = pkg.flash_attention_n(q2, k2, v.detach(), softmax_n_param=1.0, scale=64.0, is_causal=causal)
+    assert (out.float() - out2.float()).abs().max().item() <= 2e-3
+    qf, kf, vf = (t.detach().float().cpu() for t in (q, k, v))
+    want = ref_attention_n(qf, kf, vf, softmax_n_param=1.0, scale=64.0, is_causal=causal)
+    assert (out.float().cpu() - want).abs().max().item() <= 1e-2
+
+
 # ---------------------------------------------------------------- grouped-query attention (fewer K/V heads than query heads)
 @pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("kind", ["plain", "causal+keypad", "bias", "decode"])
