@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     constexpr bool PSUM = SEED >= 2 && !DROP;   // fast-path row sums from the packed weights
+    constexpr bool UNR3 = RING == 2 && D <= 64;  // direct-to-LDS loop unrolled by its three buffers
     constexpr int NT = NW * 64;
     constexpr int BM = NW * QB * 32;
     constexpr int ROWB = D * 2;
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         }
     };
     auto stage_load = [&](int t, auto SET) {
-        constexpr int S_ = decltype(SET)::value;
+        constexpr int S_ = RING == 2 ? 0 : decltype(SET)::value;   // RING 2 passes its LDS buffer index here and has no register sets
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             // ABL 10: every staging load fetches tile 0 (same instructions, always an L2 hit): separates instruction cost from memory latency
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         }
     };
     auto stage_store = [&](int buf, auto SET) {
-        constexpr int S_ = decltype(SET)::value;
+        constexpr int S_ = RING == 2 ? 0 : decltype(SET)::value;   // RING 2 passes its LDS buffer index here and has no register sets
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             *LDS_PTR(u32x4, ldsK + buf * TILEB + ldsoff[i]) = stK[S_][i];
@@ -371,9 +372,13 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     auto tile_body = [&](const int t, auto LSET, auto SSET) {
         // RING 1: the loop is unrolled by two (even tile: LSET = set 0, odd tile: LSET = set 1), so the LDS buffer index is a
         // compile-time constant there and buf*TILEB folds into the ds_read immediate offsets instead of two VALU per read
-        const int buf = (ABL == 6 || ABL == 7) ? 0 : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1)));
+        // RING 2: the loop is unrolled by three and LSET carries the tile's LDS buffer (t % 3) as a compile-time constant, so the
+        // buffer offset folds into the ds_read immediates and the DMA's M0 values instead of two VALU per LDS address
+        // (D <= 64 only: at D = 128 the tripled loop body measured 1-2 % slower, instruction cache)
+        const int buf = (ABL == 6 || ABL == 7) ? 0 : (UNR3 ? decltype(LSET)::value : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1))));
+        const int buf2 = UNR3 ? (decltype(LSET)::value + 2) % 3 : (t + 2) % 3;   // RING 2: buffer of the tile requested now
         const int k0 = t * KT;
-        if (RING == 2 && !VEC) stage_direct(t + 2, (t + 2) % 3);   // past-the-end tiles are out of range for the descriptor
+        if (RING == 2 && !VEC) stage_direct(t + 2, buf2);   // past-the-end tiles are out of range for the descriptor
         else if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
 
         uint64_t kp_bits = ~0ull;
@@ -422,7 +427,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before the next one is requested
             gen_dma(t + 1);                                        // past-the-end tiles are out of range: zeros
-            if (RING == 2) stage_direct(t + 2, (t + 2) % 3);
+            if (RING == 2) stage_direct(t + 2, buf2);
             else stage_load(t + 1 + RING, LSET);
         }
         if (!skip) {
@@ -700,6 +705,15 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         for (int t = 0; t < ntiles; t += 2) {
             tile_body(t, Set0{}, Set1{});       // even tile: tile t+1 sits in set 1, tile t+2 goes to set 0
             if (t + 1 < ntiles) tile_body(t + 1, Set1{}, Set0{});
+        }
+    } else if (UNR3) {
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        using B2 = std::integral_constant<int, 2>;
+        for (int t = t_begin; t < ntiles; t += 3) {   // t_begin is a multiple of 3 (split-K: tps is a multiple of 6)
+            tile_body(t, B0{}, B0{});
+            if (t + 1 < ntiles) tile_body(t + 1, B1{}, B1{});
+            if (t + 2 < ntiles) tile_body(t + 2, B2{}, B2{});
         }
     } else {
         for (int t = t_begin; t < ntiles; ++t) tile_body(t, Set0{}, Set0{});
