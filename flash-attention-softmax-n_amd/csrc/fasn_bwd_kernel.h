@@ -123,6 +123,9 @@ struct TileDma {
 
 // ---------------------------------------------------------------------------------------------
 // dQ: workgroup = 4 waves x QB x 32 query rows, loop over 64-key tiles.
+#ifndef FASN_BWD_UNROLL2
+#define FASN_BWD_UNROLL2 1
+#endif
 #ifndef FASN_DQ_SEED_D128
 #define FASN_DQ_SEED_D128 2
 #endif
@@ -327,8 +330,12 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, 0, 0);
     }
 
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
+    // the loop is unrolled by its two LDS buffers: the buffer offset is a compile-time constant and folds into the ds_read
+    // immediates instead of costing VALU adds per LDS address (FASN_BWD_UNROLL2 = 0: dynamic buffer index, for A/B)
+    using Buf0 = std::integral_constant<int, 0>;
+    using Buf1 = std::integral_constant<int, FASN_BWD_UNROLL2 ? 1 : 0>;
+    auto ktile_body = [&](const int t, auto BUF_) {
+        const int buf = FASN_BWD_UNROLL2 ? decltype(BUF_)::value : (t & 1);
         const int k0 = t * KT;
         uint64_t kp_bits = ~0ull;
         if (KP) {
@@ -506,6 +513,14 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
             tsV.lstore(stV, ldsV + (buf ^ 1) * TILEB);
         }
         __syncthreads();
+    };
+    if constexpr (FASN_BWD_UNROLL2 != 0) {
+        for (int t = 0; t < ntiles; t += 2) {
+            ktile_body(t, Buf0{});
+            if (t + 1 < ntiles) ktile_body(t + 1, Buf1{});
+        }
+    } else {
+        for (int t = 0; t < ntiles; ++t) ktile_body(t, Buf0{});
     }
 
     if (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the image requested for the tile past the end has landed
@@ -755,8 +770,12 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         }
         kp_none = !__any(any);
     }
-    for (int tq = tq0; tq < ntq; ++tq) {
-        const int buf = (tq - tq0) & 1;
+    // the loop is unrolled by its two LDS buffers: the buffer offset is a compile-time constant and folds into the ds_read
+    // immediates instead of costing VALU adds per LDS address (FASN_BWD_UNROLL2 = 0: dynamic buffer index, for A/B)
+    using Buf0 = std::integral_constant<int, 0>;
+    using Buf1 = std::integral_constant<int, FASN_BWD_UNROLL2 ? 1 : 0>;
+    auto qtile_body = [&](const int tq, auto BUF_) {
+        const int buf = FASN_BWD_UNROLL2 ? decltype(BUF_)::value : ((tq - tq0) & 1);
         const int r0 = tq * QT;
         if (tq + 1 < ntq) {
             if (DIRECT) {   // buffer buf^1 was released by the barrier that ended the previous tile
@@ -915,6 +934,14 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         }
         if (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next Q / dO tiles have landed
         __syncthreads();
+    };
+    if constexpr (FASN_BWD_UNROLL2 != 0) {
+        for (int tq = tq0; tq < ntq; tq += 2) {
+            qtile_body(tq, Buf0{});
+            if (tq + 1 < ntq) qtile_body(tq + 1, Buf1{});
+        }
+    } else {
+        for (int tq = tq0; tq < ntq; ++tq) qtile_body(tq, Buf0{});
     }
 
     char* dkbase = bp.dk + (b * bp.dks[0] + h * bp.dks[1]) * 2;
