@@ -23,6 +23,9 @@
 #include <type_traits>
 #include "fasn_common.h"
 
+#ifndef FASN_FWD_UNR2
+#define FASN_FWD_UNR2 1
+#endif
 namespace fasn {
 
 // MODE_GENERAL: mask and/or bias through 4-key vector (buffer) loads - needs key stride 1 and aligned rows (bias_vec /
@@ -88,6 +91,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     using vec8 = typename E::vec8;
     constexpr bool PSUM = SEED >= 2 && !DROP;   // fast-path row sums from the packed weights
     constexpr bool UNR3 = RING == 2 && D <= 64;  // direct-to-LDS loop unrolled by its three buffers
+    constexpr bool UNR2 = RING == 0 && ABL == 0 && FASN_FWD_UNR2;   // single-set staging: loop unrolled by its two LDS buffers
     constexpr int NT = NW * 64;
     constexpr int BM = NW * QB * 32;
     constexpr int ROWB = D * 2;
@@ -208,7 +212,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         }
     };
     auto stage_load = [&](int t, auto SET) {
-        constexpr int S_ = RING == 2 ? 0 : decltype(SET)::value;   // RING 2 passes its LDS buffer index here and has no register sets
+        constexpr int S_ = RING == 1 ? decltype(SET)::value : 0;   // RING 0 / 2 pass their LDS buffer index here (one or no register set)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             // ABL 10: every staging load fetches tile 0 (same instructions, always an L2 hit): separates instruction cost from memory latency
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         }
     };
     auto stage_store = [&](int buf, auto SET) {
-        constexpr int S_ = RING == 2 ? 0 : decltype(SET)::value;   // RING 2 passes its LDS buffer index here and has no register sets
+        constexpr int S_ = RING == 1 ? decltype(SET)::value : 0;   // RING 0 / 2 pass their LDS buffer index here (one or no register set)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             *LDS_PTR(u32x4, ldsK + buf * TILEB + ldsoff[i]) = stK[S_][i];
@@ -375,7 +379,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         // RING 2: the loop is unrolled by three and LSET carries the tile's LDS buffer (t % 3) as a compile-time constant, so the
         // buffer offset folds into the ds_read immediates and the DMA's M0 values instead of two VALU per LDS address
         // (D <= 64 only: at D = 128 the tripled loop body measured 1-2 % slower, instruction cache)
-        const int buf = (ABL == 6 || ABL == 7) ? 0 : (UNR3 ? decltype(LSET)::value : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1))));
+        const int buf = (ABL == 6 || ABL == 7) ? 0 : ((UNR3 || UNR2) ? decltype(LSET)::value : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1))));
         const int buf2 = UNR3 ? (decltype(LSET)::value + 2) % 3 : (t + 2) % 3;   // RING 2: buffer of the tile requested now
         const int k0 = t * KT;
         if (RING == 2 && !VEC) stage_direct(t + 2, buf2);   // past-the-end tiles are out of range for the descriptor
@@ -714,6 +718,13 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             tile_body(t, B0{}, B0{});
             if (t + 1 < ntiles) tile_body(t + 1, B1{}, B1{});
             if (t + 2 < ntiles) tile_body(t + 2, B2{}, B2{});
+        }
+    } else if (UNR2) {
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        for (int t = t_begin; t < ntiles; t += 2) {   // t_begin is even
+            tile_body(t, B0{}, B0{});
+            if (t + 1 < ntiles) tile_body(t + 1, B1{}, B1{});
         }
     } else {
         for (int t = t_begin; t < ntiles; ++t) tile_body(t, Set0{}, Set0{});
