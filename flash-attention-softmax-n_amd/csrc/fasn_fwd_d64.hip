@@ -32,7 +32,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (v == 0) {
         // auto (what ABI callers get), measured on MI355X at (8,16,4096,64), 200 launches each. All plain / causal / key-padding
         // kernels run with seeded accumulators (Q pre-scaled, S starts at -m, row sums by v_dot2c on the packed weights):
-        //   plain : QB=2 / 2 waves per SIMD / direct-to-LDS  1058 TFLOP/s  (unseeded two-set ring 1005; QB=1 / 3 waves 983)
+        //   plain : QB=2 / 2 waves per SIMD / direct-to-LDS  1058 TFLOP/s  (unseeded two-set ring 1005; QB=1 / 3 waves 983); 1130 with the loop unrolled by its buffers
         //   causal: QB=1 / 3 waves per SIMD / direct-to-LDS   772 TFLOP/s  (unseeded 734; QB=2 719: coarser diagonal, worse tail)
         const long blocks_qb2 = (long)((p.Sq + 255) / 256) * p.B * p.H;
         v = ((l.mode == MODE_PLAIN || (l.mode == MODE_KEYPAD && !p.causal)) && blocks_qb2 >= 512 && p.Sq >= 256) ? 85 : 86;   // 512 = one full round of two workgroups per CU
