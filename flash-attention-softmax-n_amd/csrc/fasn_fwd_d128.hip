@@ -63,7 +63,9 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     const long blocks256 = (long)((p.Sq + 255) / 256) * p.B * p.H;
     // Both with seeded accumulators (Q pre-scaled, S starts at -m) and packed row sums: 1137 vs 1093 TFLOP/s at C4's shape,
     // 680 vs 631 at (1,16,2048,128) where the 4-wave kernel with direct-to-LDS staging runs.
-    if (l.variant == 0 && blocks256 >= 512 && p.Sq >= 256) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 1, 2>(p, l.mode, s);
+    // The 8-wave kernel stages K/V straight to LDS with the loop unrolled by its three buffers: 1164 vs 1112 TFLOP/s for the two-set
+    // register ring (variant 80), causal 1034 vs 984.
+    if (l.variant == 0 && blocks256 >= 512 && p.Sq >= 256) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 2, 2>(p, l.mode, s);
     return launch_fwd_cfg<Tag, 128, 1, 2, 4, 2, 2>(p, l.mode, s);
 }
 int launch_fwd_d128(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {

@@ -23,6 +23,9 @@
 #include <type_traits>
 #include "fasn_common.h"
 
+#ifndef FASN_UNR3_D128
+#define FASN_UNR3_D128 1
+#endif
 #ifndef FASN_FWD_UNR2
 #define FASN_FWD_UNR2 1
 #endif
@@ -90,7 +93,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     constexpr bool PSUM = SEED >= 2 && !DROP;   // fast-path row sums from the packed weights
-    constexpr bool UNR3 = RING == 2 && D <= 64;  // direct-to-LDS loop unrolled by its three buffers
+    constexpr bool UNR3 = RING == 2 && (D <= 64 || (FASN_UNR3_D128 && NW == 8 && MODE != MODE_GENERAL && MODE != MODE_GENERAL_B && MODE != MODE_GENERAL_M));  // direct-to-LDS loop unrolled by its three buffers
     constexpr bool UNR2 = RING == 0 && ABL == 0 && FASN_FWD_UNR2;   // single-set staging: loop unrolled by its two LDS buffers
     constexpr int NT = NW * 64;
     constexpr int BM = NW * QB * 32;
@@ -378,7 +381,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         // compile-time constant there and buf*TILEB folds into the ds_read immediate offsets instead of two VALU per read
         // RING 2: the loop is unrolled by three and LSET carries the tile's LDS buffer (t % 3) as a compile-time constant, so the
         // buffer offset folds into the ds_read immediates and the DMA's M0 values instead of two VALU per LDS address
-        // (D <= 64 only: at D = 128 the tripled loop body measured 1-2 % slower, instruction cache)
+        // (D <= 64 and the plain 8-wave D = 128 kernel; the D = 128 mask / bias and 4-wave kernels measured 1-2 % slower with the
+        // tripled loop body, instruction cache)
         const int buf = (ABL == 6 || ABL == 7) ? 0 : ((UNR3 || UNR2) ? decltype(LSET)::value : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1))));
         const int buf2 = UNR3 ? (decltype(LSET)::value + 2) % 3 : (t + 2) % 3;   // RING 2: buffer of the tile requested now
         const int k0 = t * KT;
