@@ -1,41 +1,147 @@
 #!/usr/bin/env python
-"""bench.py — headline benchmark of the hot path (BASELINE.json): attn-ops/s of flash_attention_n forward at
+"""bench.py — headline benchmark of the hot path (BASELINE.json): attn-ops/s of flash_attention_n at
 (B=8, H=16, S=4096, D=64) bf16, n=1, non-causal, on N replicated GPUs (no sharding, no RCCL on the data path).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...)
+  python bench.py --gpus N --steps K --warmup W [--workload m0|c2|c3|c4|c5] [--pass fwd|bwd|fwdbwd]
 
-A step = one forward pass of the fused kernel over the whole (8,16,4096,64) batch, inputs resident in HBM.
-Rank 0 prints ONE JSON line; `value` = total attn-ops/s over all replicas = N * K / max-over-ranks(wall time of K steps).
-Also in the line: `roofline` (dominant kernel vs the dense bf16 MFMA peak, duration from HIP events on the launch stream)
-and, at N=1, `cpu_baseline` (the oracle's eager restatement of slow_attention_n timed on the host cores on a bounded
-sample) plus `max_abs_err` of the GPU result against that same oracle output.
+N > 1: bench.py launches its own N replica processes (one per GPU, gloo control plane over 127.0.0.1) when it is started
+without WORLD_SIZE; started under `python -m torch.distributed.run --nproc-per-node N ...` it joins that world instead.
+Either way WORLD_SIZE must equal --gpus and N GPUs must be visible, or the run FAILS (it never reports fewer GPUs than asked).
+
+A step = one pass of the hot path over the whole batch, inputs resident in HBM:
+  --pass fwd     one flash_attention_n forward (Python front end -> ctypes -> fasn_fwd)                     [default, the metric]
+  --pass fwdbwd  forward + backward through autograd (fasn_fwd, then fasn_bwd = delta + dQ + dK/dV kernels)
+  --pass bwd     the backward alone: one fasn_bwd call on saved (o, lse) with preallocated gradients
+Rank 0 prints ONE JSON line; `value` = whole-job steps/s = N * K / max-over-ranks(wall time of K steps).
+In the line: `roofline` (dominant kernel(s) vs the dense MFMA peak, duration from events on the launch stream, HBM traffic
+from the committed PMC pass of THIS libfasn.so build or null), at N=1 `cpu_baseline` (the oracle's restatement of
+slow_attention_n on the host cores, bounded sample) and `max_abs_err` against that oracle; the default forward run also
+carries `backward` / `fwdbwd` objects (same K and W, measured after the headline's timed region).
 """
 import argparse
-import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (B, H, S, D, dtype, n, causal)
-    "m0": (8, 16, 4096, 64, torch.bfloat16, 1.0, False),   # the shape BASELINE.json's metric is quoted on
-    "c2": (8, 16, 1024, 64, torch.bfloat16, 1.0, False),
-    "c3": (8, 16, 4096, 64, torch.float16, 1.0, True),
-    "c5": (64, 16, 4096, 64, torch.bfloat16, 1.0, True),
-    "c4": (4, 32, 8192, 128, torch.bfloat16, 0.5, False),   # + dense ALiBi bias [H,L,S] and key-padding mask [B,1,1,S]
+    "m0": (8, 16, 4096, 64, "bf16", 1.0, False),   # the shape BASELINE.json's metric is quoted on
+    "c2": (8, 16, 1024, 64, "bf16", 1.0, False),
+    "c3": (8, 16, 4096, 64, "f16", 1.0, True),
+    "c5": (64, 16, 4096, 64, "bf16", 1.0, True),
+    "c4": (4, 32, 8192, 128, "bf16", 0.5, False),   # + dense ALiBi bias [H,L,S] and key-padding mask [B,1,1,S]
 }
 PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak, MI355X (MI355X_MICROARCH.md)
+# GEMM-equivalents (one = 2*B*H*Sq*Sk*D flops): forward 2 (QK^T, PV); backward 5 in the textbook algorithm (S, dP, dV, dK, dQ),
+# 7 executed by the deterministic two-kernel split (S and dP are recomputed by both the dQ and the dK/dV kernel)
+GEMMS = {"fwd": (2, 2), "bwd": (5, 7), "fwdbwd": (7, 9)}
 
 
 def fwd_flops(B, H, S, D, causal):
     return 4.0 * B * H * D * (S * (S + 1) / 2 if causal else S * S)
+
+
+def pass_flops(which, B, H, S, D, causal):
+    """(algorithmic, executed) flops of one step of `which`"""
+    g = fwd_flops(B, H, S, D, causal) / 2.0
+    return GEMMS[which][0] * g, GEMMS[which][1] * g
+
+
+def lib_sha256():
+    path = os.path.join(ROOT, "flash-attention-softmax-n_amd", "libfasn.so")
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def pmc_traffic(workload, which):
+    """HBM bytes per launch from the committed rocprofv3 --pmc pass — only if it was taken with THIS build of libfasn.so."""
+    prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        d = json.load(open(prof))
+        if d.get("libfasn_sha256") != lib_sha256():
+            return None
+        return d.get(f"{workload}:{which}", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_replicas(args):
+    """--gpus N without a launcher: start N copies of this script, one per GPU, and relay rank 0's line."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(rcs):
+        sys.exit(f"bench.py: replica exit codes {rcs}")
+
+
+class Control:
+    """control plane of the replicas: a barrier and the MAX of one scalar (gloo over loopback); the data path has no collective"""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.world == 1:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def timed(ctl, step, sync, steps, warmup):
+    """W untimed warm-up steps, then EXACTLY K steps between barrier + device sync on both sides; MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    sync()
+    ctl.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    ctl.barrier()
+    return ctl.max(dt)
 
 
 def main():
@@ -44,117 +150,182 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="m0", choices=sorted(WORKLOADS))
+    ap.add_argument("--pass", dest="which", default="fwd", choices=["fwd", "bwd", "fwdbwd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-passes", action="store_true", help="default forward run: skip the backward / fwdbwd objects")
+    ap.add_argument("--stub-step-ms", type=float, default=None,
+                    help="testing only: replace the GPU step by a sleep of this many ms (exercises launch + aggregation on CPU)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_replicas(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    import torch.distributed as dist
-    if world > 1:
-        # control plane only (barrier + max of one float): gloo over loopback; the data path has no collective
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    dev = torch.device("cuda", torch.cuda.current_device())
+    if world != args.gpus:
+        sys.exit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a different GPU count than asked")
 
-    import flash_attention_softmax_n_amd as pkg
-    from flash_attention_softmax_n_amd import synth
+    B, H, S, D, dname, n, causal = WORKLOADS[args.workload]
+    stub = args.stub_step_ms is not None
+    ctl = Control(rank, world)
+    extra = {}
+    kernel_ms = None
+    if stub:
+        def step():
+            time.sleep(args.stub_step_ms * 1e-3 * (1 + rank))   # rank-dependent: the MAX over ranks is rank N-1's time
+        dt = timed(ctl, step, lambda: None, args.steps, args.warmup)
+    else:
+        import ctypes  # noqa: F401
+        import torch
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+        if torch.cuda.device_count() < world:
+            sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dname]
 
-    B, H, S, D, dtype, n, causal = WORKLOADS[args.workload]
-    q, k, v = (synth.counter_normal((B, H, S, D), seed, dtype=dtype, device=dev) for seed in (101, 102, 103))
+        import flash_attention_softmax_n_amd as pkg
+        from flash_attention_softmax_n_amd import synth
+        lib, fa = pkg._lib.load(), pkg.flash_attn
+        q, k, v = (synth.counter_normal((B, H, S, D), seed, dtype=dtype, device=dev) for seed in (101, 102, 103))
+        do = synth.counter_normal((B, H, S, D), 104, std=1.0, dtype=dtype, device=dev)
+        bias = mask = None
+        if args.workload == "c4":
+            bias = synth.alibi_bias(H, S, S, dtype, device=dev)
+            mask = synth.keypad_mask(B, S, device=dev)
+        sync = torch.cuda.synchronize
+        stream = torch.cuda.current_stream().cuda_stream
+        out_holder = {}
 
-    bias = mask = None
-    if args.workload == "c4":
-        bias = synth.alibi_bias(H, S, S, dtype, device=dev)
-        mask = synth.keypad_mask(B, S, device=dev)
+        def step_fwd():
+            with torch.no_grad():
+                out_holder["o"] = pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal, attn_mask=mask, attn_bias=bias)
 
-    def step():
-        return pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal, attn_mask=mask, attn_bias=bias)
+        qg, kg, vg = (t.detach().clone().requires_grad_() for t in (q, k, v))
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            out = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            dist.barrier()
-            t = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        def step_fwdbwd():
+            qg.grad = kg.grad = vg.grad = None
+            o = pkg.flash_attention_n(qg, kg, vg, softmax_n_param=n, is_causal=causal, attn_mask=mask, attn_bias=bias)
+            o.backward(do)
 
-    # dominant-kernel duration: HIP events on the launch stream around back-to-back launches of the same kernel
-    fa = pkg.flash_attn
-    o2 = torch.empty_like(q)
-    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
-    a = pkg._lib.FwdArgs()
-    fa._fill_fwd(a, q, k, v, o2, lse, None if mask is None else mask.expand(B, H, S, S).view(torch.uint8),
-                 None if bias is None else bias.unsqueeze(0).expand(B, H, S, S), n, 1.0 / D ** 0.5, causal)
-    ms = ctypes.c_float(0.0)
-    stream = torch.cuda.current_stream().cuda_stream
-    pkg._lib.check(pkg._lib.load().fasn_time_fwd(a, stream, 10, max(200, args.steps), ctypes.byref(ms)), "fasn_time_fwd")
-    kernel_ms = float(ms.value)
-    flops = fwd_flops(B, H, S, D, causal)
-    achieved = flops / (kernel_ms * 1e-3) / 1e12
+        # the backward alone: one fasn_bwd (delta + dQ + dK/dV) on the saved forward state, gradients preallocated
+        o_s = torch.empty_like(q)
+        lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+        m8 = None if mask is None else mask.expand(B, H, S, S).view(torch.uint8)
+        b4 = None if bias is None else bias.unsqueeze(0).expand(B, H, S, S)
+        fargs = pkg._lib.FwdArgs()
+        fa._fill_fwd(fargs, q, k, v, o_s, lse, m8, b4, n, 1.0 / D ** 0.5, causal)
+        pkg._lib.check(lib.fasn_fwd(fargs, stream), "fasn_fwd")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        bargs = pkg._lib.BwdArgs()
+        fa._fill_fwd(bargs.fwd, q, k, v, o_s, lse, m8, b4, n, 1.0 / D ** 0.5, causal)
+        bargs.dout, bargs.dq, bargs.dk, bargs.dv = (fa._view4(t) for t in (do, dq, dk, dv))
+        bargs.delta = delta.data_ptr()
+
+        def step_bwd():
+            pkg._lib.check(lib.fasn_bwd(bargs, stream), "fasn_bwd")
+
+        steps_of = {"fwd": step_fwd, "bwd": step_bwd, "fwdbwd": step_fwdbwd}
+        dt = timed(ctl, steps_of[args.which], sync, args.steps, args.warmup)
+
+        def kernel_time(fn, iters):
+            """average duration of back-to-back launches: events on the launch stream (torch's current stream IS the stream
+            the ctypes call launches on), >= 200 launches so the clocks settle"""
+            for _ in range(10):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / iters
+
+        raw = {"fwd": lambda: lib.fasn_fwd(fargs, stream), "bwd": lambda: lib.fasn_bwd(bargs, stream)}
+        if args.which in raw:
+            kernel_ms = kernel_time(raw[args.which], max(200 if args.which == "fwd" else 60, args.steps))
+        else:
+            kernel_ms = kernel_time(raw["fwd"], 100) + kernel_time(raw["bwd"], 60)
+
+        if args.which == "fwd" and args.workload == "m0" and world == 1 and not args.no_extra_passes:
+            # driver-visible backward numbers next to the headline (same K and W, measured after the headline's timed region)
+            for w in ("bwd", "fwdbwd"):
+                dtw = timed(ctl, steps_of[w], sync, args.steps, args.warmup)
+                kms = kernel_time(raw["bwd"], 60) if w == "bwd" else None
+                alg, exe = pass_flops(w, B, H, S, D, causal)
+                extra["backward" if w == "bwd" else "fwdbwd"] = {
+                    "steps_per_s": args.steps / dtw, "ms_per_step": dtw / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                    "algorithmic_tflops": alg / (dtw / args.steps) / 1e12, "executed_tflops": exe / (dtw / args.steps) / 1e12,
+                    "frac_of_peak_algorithmic": alg / (dtw / args.steps) / 1e12 / PEAK_TFLOPS,
+                    **({"kernels_ms": kms, "kernels_frac_of_peak_executed": exe / (kms * 1e-3) / 1e12 / PEAK_TFLOPS} if kms else {})}
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        ctl.close()
         return
 
     ops_per_s = world * args.steps / dt
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "pmc_latest.json")  # per-launch HBM bytes from a committed rocprofv3 --pmc run
-    if os.path.exists(prof):
-        try:
-            traffic = json.load(open(prof)).get(args.workload, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    alg, exe = pass_flops(args.which, B, H, S, D, causal)
+    names = {"fwd": "forward", "bwd": "backward", "fwdbwd": "forward+backward"}
     line = {
-        "metric": "attn-ops/sec (flash_attention_n forward)", "value": ops_per_s, "unit": "attn-ops/s",
+        "metric": f"attn-ops/sec (flash_attention_n {names[args.which]})", "value": ops_per_s, "unit": "attn-ops/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {torch.bfloat16: "bf16", torch.float16: "f16"}[dtype], "data": "synthetic",
-        "config": {"workload": f"{args.workload}: flash_attention_n fwd (B={B},H={H},S={S},D={D}) n={n} causal={causal}",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: flash_attention_n {args.which} (B={B},H={H},S={S},D={D}) n={n} causal={causal}"
+                               + (" + ALiBi bias [H,L,S] + key-padding mask [B,1,1,S]" if args.workload == "c4" else ""),
                    "parallelism": f"replicas x{world} (no sharding, no collective)",
                    "output_elements_per_s": ops_per_s * B * H * S * D,
                    "score_elements_per_s": ops_per_s * B * H * S * S * (0.5 if causal else 1.0)},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
-                     "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops},
     }
+    if stub:
+        line["data"] = "stub (no GPU work: launch + aggregation test)"
+    else:
+        achieved = alg / (kernel_ms * 1e-3) / 1e12
+        line["roofline"] = {
+            "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
+            "traffic": pmc_traffic(args.workload, args.which), "kernel_ms": kernel_ms,
+            "kernels": {"fwd": "fasn_fwd_kernel", "bwd": "fasn_bwd_delta + fasn_bwd_dq + fasn_bwd_dkdv", "fwdbwd": "fasn_fwd_kernel + the three backward kernels"}[args.which],
+            "algorithmic_flops_per_launch": alg, "executed_flops_per_launch": exe,
+            "gemm_equivalents": {"algorithmic": GEMMS[args.which][0], "executed": GEMMS[args.which][1]},
+            "frac_executed": exe / (kernel_ms * 1e-3) / 1e12 / PEAK_TFLOPS}
+        line.update(extra)
 
-    if world == 1 and not args.no_cpu_baseline:
-        # CPU baseline + accuracy on a bounded sample: batch 0, all heads, through the oracle's eager restatement of
+    if not stub and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline + accuracy on a bounded sample: batch 0, a few heads, through the oracle's eager restatement of
         # slow_attention_n in the native dtype (exactly what the reference runs on CPU), all host threads.
+        import platform
+        import torch
         from oracle.ref_attention import ref_attention_n
         hs = H if S <= 4096 else 2
         qc, kc, vc = (t[0:1, :hs].cpu() for t in (q, k, v))
         threads = torch.get_num_threads()
-        t1 = time.perf_counter()
         bc = None if bias is None else bias[:hs].cpu()
         mc = None if mask is None else mask[0:1].cpu()
+        t1 = time.perf_counter()
         ref = ref_attention_n(qc, kc, vc, softmax_n_param=n, is_causal=causal, attn_bias=bc, attn_mask=mc)
         cpu_dt = time.perf_counter() - t1
         frac = hs / (B * H)
-        line["cpu_baseline"] = {"value": frac / cpu_dt, "unit": "attn-ops/s", "cores": threads, "kind": "port",
-                                "sample": f"batch 0, heads 0..{hs - 1} of the same inputs ({hs}/{B * H} of one op), {cpu_dt:.2f} s, "
-                                          f"scaled linearly; oracle/ref_attention.py (eager {line['dtype']}, as slow_attention_n)"}
+        cpu_model = platform.processor() or "unknown"
+        try:
+            cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            pass
+        line["cpu_baseline"] = {"value": frac / cpu_dt, "unit": "attn-ops/s (forward)", "cores": threads, "kind": "port", "extrapolated": True,
+                                "cpu": cpu_model,
+                                "sample": f"EXTRAPOLATED: batch 0, heads 0..{hs - 1} of the same inputs ({hs}/{B * H} of one forward op) took {cpu_dt:.2f} s, "
+                                          f"scaled linearly x{B * H // hs}; oracle/ref_attention.py (eager {dname}, as slow_attention_n)"}
+        out = out_holder.get("o")
+        if out is None:
+            step_fwd()
+            out = out_holder["o"]
         line["max_abs_err"] = float((out[0:1, :hs].float().cpu() - ref.float()).abs().max())
         ref32 = ref_attention_n(qc[:, :2].float(), kc[:, :2].float(), vc[:, :2].float(), softmax_n_param=n, is_causal=causal,
                                 attn_bias=None if bc is None else bc[:2].float(), attn_mask=mc)
         line["max_abs_err_vs_fp32_oracle"] = float((out[0:1, :2].float().cpu() - ref32).abs().max())
     print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    ctl.close()
 
 
 if __name__ == "__main__":

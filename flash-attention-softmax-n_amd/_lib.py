@@ -18,7 +18,7 @@ FASN_BIAS_NONE, FASN_BIAS_SAME, FASN_BIAS_F32 = 0, 1, 2
 EXPORTS = (
     "fasn_abi_version", "fasn_strerror", "fasn_supported", "fasn_fwd", "fasn_fwd_workspace_bytes", "fasn_fwd_ws",
     "fasn_bwd_workspace_bytes", "fasn_bwd",
-    "fasn_softmax_n_fwd", "fasn_softmax_n_bwd", "fasn_moments", "fasn_time_fwd", "fasn_time_bwd",
+    "fasn_softmax_n_fwd", "fasn_softmax_n_bwd", "fasn_moments",
 )
 
 
@@ -89,10 +89,6 @@ def load():
     lib.fasn_softmax_n_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p]
     lib.fasn_moments.restype = c_int32
     lib.fasn_moments.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p]
-    lib.fasn_time_fwd.restype = c_int32
-    lib.fasn_time_fwd.argtypes = [POINTER(FwdArgs), c_void_p, c_int32, c_int32, POINTER(c_float)]
-    lib.fasn_time_bwd.restype = c_int32
-    lib.fasn_time_bwd.argtypes = [POINTER(BwdArgs), c_void_p, c_int32, c_int32, POINTER(c_float)]
     ver = lib.fasn_abi_version()
     if ver != FASN_ABI_VERSION:
         raise ImportError(f"libfasn ABI version {ver} != expected {FASN_ABI_VERSION}; rebuild csrc/")

@@ -1,8 +1,7 @@
 // fasn_api.hip — the C ABI of libfasn (include/fasn.h): argument validation, parameter packing, dispatch.
-// No allocation, no synchronisation (the fasn_time_* helpers excepted: they exist to time launches).
+// No allocation, no synchronisation, no environment variables: every exported symbol is declared in include/fasn.h.
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include <stdlib.h>
 #include "fasn.h"
 #include "fasn_launch.h"
 #include "fasn_bwd_launch.h"
@@ -26,15 +25,6 @@ int check_view(const fasn_view4& v, bool required, int esize = 2) {
     for (int i = 0; i < 3; ++i)
         if (v.stride[i] % (16 / esize) != 0) return FASN_EALIGN;
     return FASN_OK;
-}
-
-int internal_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("FASN_FWD_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
 }
 
 int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
@@ -144,7 +134,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     // The vector kernels multiply Q (or K) by c = scale*log2e in the operand type before the MFMAs. In fp16 a large scale could
     // push an otherwise representable operand past 65504 there: such calls take the element-load kernels, which scale in fp32.
     if (a->dtype == FASN_DTYPE_F16 && fabsf(p.c) > 8.f) l.mode = MODE_GENERAL_SLOW;
-    l.variant = internal_variant();
+    l.variant = 0;
     p.nsplit = 1;
     p.tps = 0;
     p.part_o = nullptr;
@@ -249,7 +239,8 @@ int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_byt
     return dispatch_fwd(p, l, (hipStream_t)stream);
 }
 
-// internal: forward with an explicit tuning variant (used by tools/fasn_harness)
+#ifdef FASN_DEV_VARIANTS
+// developer library only (tools/libfasn_dev.so): forward with an explicit tuning variant, used by tools/fasn_harness
 int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant) {
     FwdParams p;
     FwdLaunch l;
@@ -258,6 +249,7 @@ int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int varian
     l.variant = variant;
     return dispatch_fwd(p, l, (hipStream_t)stream);
 }
+#endif
 
 size_t fasn_bwd_workspace_bytes(const fasn_bwd_args* args) {
     (void)args;
@@ -315,50 +307,6 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
     }
     if (l.dtype == FASN_DTYPE_F32) return launch_bwd_f32(p, l, (hipStream_t)stream);
     return launch_bwd(p, l, (hipStream_t)stream);
-}
-
-int fasn_time_fwd(const fasn_fwd_args* args, fasn_stream_t stream, int32_t warmup, int32_t iters, float* ms_per_iter) {
-    if (ms_per_iter == nullptr || iters <= 0) return FASN_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    for (int i = 0; i < warmup; ++i) {
-        const int rc = fasn_fwd(args, stream);
-        if (rc) return rc;
-    }
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FASN_ELAUNCH;
-    (void)hipEventRecord(e0, s);
-    int rc = 0;
-    for (int i = 0; i < iters && rc == 0; ++i) rc = fasn_fwd(args, stream);
-    (void)hipEventRecord(e1, s);
-    (void)hipEventSynchronize(e1);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *ms_per_iter = ms / (float)iters;
-    return rc;
-}
-
-int fasn_time_bwd(const fasn_bwd_args* args, fasn_stream_t stream, int32_t warmup, int32_t iters, float* ms_per_iter) {
-    if (ms_per_iter == nullptr || iters <= 0) return FASN_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    for (int i = 0; i < warmup; ++i) {
-        const int rc = fasn_bwd(args, stream);
-        if (rc) return rc;
-    }
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FASN_ELAUNCH;
-    (void)hipEventRecord(e0, s);
-    int rc = 0;
-    for (int i = 0; i < iters && rc == 0; ++i) rc = fasn_bwd(args, stream);
-    (void)hipEventRecord(e1, s);
-    (void)hipEventSynchronize(e1);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *ms_per_iter = ms / (float)iters;
-    return rc;
 }
 
 }  // extern "C"

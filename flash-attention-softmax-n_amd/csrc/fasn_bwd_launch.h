@@ -11,11 +11,6 @@ int launch_bwd_d32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d128(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 
-template <typename K>
-inline void set_smem(K kern, int smem) {
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-}
-
 template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, int DROP = 0>
 int launch_bwd_one(BwdParams p, hipStream_t s) {
     const int nbh = p.f.B * p.f.H;
@@ -28,19 +23,19 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         constexpr int BM = 4 * QB * 32;
         constexpr int smem = 4 * KT * D * 2 + (MODE == MODE_GENERAL ? 4 * QB * 6144 : 0);   // + per-wave bias / mask images
         p.nblk = (p.f.Sq + BM - 1) / BM;
-        auto kern = fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q, DROP>;
-        set_smem(kern, smem);
+        constexpr auto kern = &fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q, DROP>;
+        ensure_smem<kern>(smem);
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
     }
     {   // dK, dV
         constexpr int BN = 4 * KB * 32;
         constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (MODE == MODE_GENERAL ? 2 * QT * BN * 2 : 0);
         p.nblk = (p.f.Sk + BN - 1) / BN;
-        auto kern = fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP>;
-        set_smem(kern, smem);
+        constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP>;
+        ensure_smem<kern>(smem);
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
     }
-    return hipGetLastError() == hipSuccess ? 0 : -6;
+    return launch_rc();
 }
 
 template <typename Tag, int D, int QB, int KB, int OCC_Q, int OCC_K>

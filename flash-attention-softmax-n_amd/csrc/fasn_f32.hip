@@ -9,10 +9,10 @@ template <int D, int MODE>
 static int fwd_one(FwdParams p, hipStream_t s) {
     constexpr int smem = 4 * 64 * D * 4;
     p.nqblk = (p.Sq + 127) / 128;
-    auto kern = fasn_f32_fwd_kernel<D, MODE>;
-    set_smem(kern, smem);
+    constexpr auto kern = &fasn_f32_fwd_kernel<D, MODE>;
+    ensure_smem<kern>(smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -6;
+    return launch_rc();
 }
 
 template <int D, int MODE>
@@ -26,18 +26,18 @@ static int bwd_one(BwdParams p, hipStream_t s) {
     {
         constexpr int smem = 4 * 64 * D * 4;
         p.nblk = (p.f.Sq + 127) / 128;
-        auto kern = fasn_f32_dq_kernel<D, MODE>;
-        set_smem(kern, smem);
+        constexpr auto kern = &fasn_f32_dq_kernel<D, MODE>;
+        ensure_smem<kern>(smem);
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
     }
     {
         constexpr int smem = 4 * 64 * D * 4 + 4 * 64 * 4;
         p.nblk = (p.f.Sk + 127) / 128;
-        auto kern = fasn_f32_dkdv_kernel<D, MODE>;
-        set_smem(kern, smem);
+        constexpr auto kern = &fasn_f32_dkdv_kernel<D, MODE>;
+        ensure_smem<kern>(smem);
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
     }
-    return hipGetLastError() == hipSuccess ? 0 : -6;
+    return launch_rc();
 }
 
 int launch_fwd_f32(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {

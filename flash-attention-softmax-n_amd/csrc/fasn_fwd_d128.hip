@@ -1,8 +1,10 @@
 // D = 128 forward instantiations (QB=1: 32 query rows per wave; O^T alone is 64 registers).
+// A/B tuning points and ablations: FASN_DEV_VARIANTS builds only (tools/libfasn_dev.so), see fasn_launch.h.
 #include "fasn_launch.h"
 namespace fasn {
 template <typename Tag>
 static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+#ifdef FASN_DEV_VARIANTS
     if (l.variant == 1) {   // A/B: unseeded
         switch (l.mode) {
             case MODE_GENERAL: case MODE_GENERAL_B: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2>(p, s);
@@ -10,6 +12,7 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
             default: break;
         }
     }
+#endif
     switch (l.mode) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);
         case MODE_GENERAL_B: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);   // the bias-only instantiation spills (37 VGPRs) at D = 128
@@ -21,6 +24,7 @@ template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (p.drop_thr) return launch_fwd_drop<Tag, 128, 1, 1>(p, l.mode, s);
     if (l.mode >= MODE_GENERAL && l.mode != MODE_KEYPAD) return launch_gen<Tag>(p, l, s);   // key-padding masks ride the plain tuning points
+#ifdef FASN_DEV_VARIANTS
     if (l.variant == 1) return launch_fwd_mode<Tag, 128, 1, 1>(p, l.mode, s);
     // A/B and ablations (tools/fasn_harness bench ... <variant>); ablation results are not attention outputs
     if (l.variant == 40) return launch_fwd_ring<Tag, 128, 1, 2>(p, l.mode, s);
@@ -57,6 +61,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.variant == 25) return launch_fwd_abl<Tag, 128, 1, 2, 5>(p, s);
     if (l.variant == 26) return launch_fwd_abl<Tag, 128, 1, 2, 6>(p, s);
     if (l.variant == 27) return launch_fwd_abl<Tag, 128, 1, 2, 7>(p, s);
+#endif
     // auto: with enough work to give every CU two 256-row blocks, one 8-wave workgroup per CU (eight waves share each staged
     // K/V tile, tiles loaded two ahead in two register sets) beats two 4-wave workgroups: 1134 vs 1014 TFLOP/s at
     // (4,32,8192,128) bf16, 886 vs 790 at (2,16,2048,128); staging + barrier cost 26 % of the 4-wave kernel at D = 128
@@ -65,7 +70,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     // 680 vs 631 at (1,16,2048,128) where the 4-wave kernel with direct-to-LDS staging runs.
     // The 8-wave kernel stages K/V straight to LDS with the loop unrolled by its three buffers: 1164 vs 1112 TFLOP/s for the two-set
     // register ring (variant 80), causal 1034 vs 984.
-    if (l.variant == 0 && blocks256 >= 512 && p.Sq >= 256) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 2, 2>(p, l.mode, s);
+    if (blocks256 >= 512 && p.Sq >= 256) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 2, 2>(p, l.mode, s);
     return launch_fwd_cfg<Tag, 128, 1, 2, 4, 2, 2>(p, l.mode, s);
 }
 int launch_fwd_d128(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {

@@ -14,10 +14,12 @@ template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (p.drop_thr) return launch_fwd_drop<Tag, 32, 2, 2>(p, l.mode, s);
     if (l.mode >= MODE_GENERAL && l.mode != MODE_KEYPAD) return launch_gen<Tag>(p, l, s);
+#ifdef FASN_DEV_VARIANTS
     if (l.variant == 80) return launch_fwd_cfg<Tag, 32, 2, 2, 4, 0, 2>(p, l.mode, s);   // seeded accumulators + packed row sums
     if (l.variant == 81) return launch_fwd_cfg<Tag, 32, 2, 2, 4, 2, 2>(p, l.mode, s);
     if (l.variant == 1) return launch_fwd_mode<Tag, 32, 2, 2>(p, l.mode, s);   // unseeded, for A/B (740 vs 796 TFLOP/s at (8,16,4096,32))
     if (l.variant == 82) return launch_fwd_cfg<Tag, 32, 2, 2, 4, 1, 2>(p, l.mode, s);   // two-set ring (800 vs 833 TFLOP/s for the unrolled direct-to-LDS loop)
+#endif
     return launch_fwd_cfg<Tag, 32, 2, 2, 4, 2, 2>(p, l.mode, s);
 }
 int launch_fwd_d32(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {

@@ -1,9 +1,11 @@
-// D = 64 forward instantiations. variant 0 = auto (the only value the C ABI uses); other values select a tuning
-// point or a developer ablation for A/B runs through tools/fasn_harness (see the switch below).
+// D = 64 forward instantiations. libfasn.so compiles the production tuning points only; the A/B tuning points and the
+// ablations (whose results are NOT attention outputs) exist in FASN_DEV_VARIANTS builds (tools/libfasn_dev.so) and are
+// selected by tools/fasn_harness through fasn_fwd_variant - nothing in the shipped library can reach them.
 #include "fasn_launch.h"
 namespace fasn {
 template <typename Tag>
 static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+#ifdef FASN_DEV_VARIANTS
     if (l.variant == 70) return launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 2>(p, s);          // A/B: 64 rows per wave
     if (l.variant == 71) return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 8>(p, s);       // A/B: 8 waves
     if (l.variant == 72) return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 4, 2>(p, s);    // A/B: direct K/V staging
@@ -16,6 +18,7 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
             default: break;
         }
     }
+#endif
     switch (l.mode) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 4, 0, 2>(p, s);
         case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_B, 2, 4, 0, 2>(p, s);
@@ -23,21 +26,10 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         default: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_SLOW, 1>(p, s);
     }
 }
+#ifdef FASN_DEV_VARIANTS
 template <typename Tag>
-static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
-    if (p.drop_thr) return launch_fwd_drop<Tag, 64, 1, 2>(p, l.mode, s);
-    if (l.mode >= MODE_GENERAL && l.mode != MODE_KEYPAD) return launch_gen<Tag>(p, l, s);   // key-padding masks ride the plain tuning points
-    const bool gen = false;  // general modes returned above
-    int v = l.variant;
-    if (v == 0) {
-        // auto (what ABI callers get), measured on MI355X at (8,16,4096,64), 200 launches each. All plain / causal / key-padding
-        // kernels run with seeded accumulators (Q pre-scaled, S starts at -m, row sums by v_dot2c on the packed weights):
-        //   plain : QB=2 / 2 waves per SIMD / direct-to-LDS  1058 TFLOP/s  (unseeded two-set ring 1005; QB=1 / 3 waves 983); 1130 with the loop unrolled by its buffers
-        //   causal: QB=1 / 3 waves per SIMD / direct-to-LDS   772 TFLOP/s  (unseeded 734; QB=2 719: coarser diagonal, worse tail)
-        const long blocks_qb2 = (long)((p.Sq + 255) / 256) * p.B * p.H;
-        v = ((l.mode == MODE_PLAIN || (l.mode == MODE_KEYPAD && !p.causal)) && blocks_qb2 >= 512 && p.Sq >= 256) ? 85 : 86;   // 512 = one full round of two workgroups per CU
-    }
-    switch (v) {
+static int dev_variant(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    switch (l.variant) {
         // ---- production tuning points
         case 100: return launch_fwd_mode<Tag, 64, 2, 2>(p, l.mode, s);
         case 1: return launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);
@@ -61,7 +53,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 82: return launch_fwd_ring<Tag, 64, 1, 2, 1, 0, 1>(p, l.mode, s);
         case 83: return launch_fwd_ring<Tag, 64, 2, 2, 2, 0, 1>(p, l.mode, s);   // + direct-to-LDS staging (no staging registers)
         case 84: return launch_fwd_ring<Tag, 64, 1, 3, 2, 0, 1>(p, l.mode, s);
-        case 85: return launch_fwd_ring<Tag, 64, 2, 2, 2, 0, 2>(p, l.mode, s);   // + row sums by v_dot2c on the packed weights
+        case 85: return launch_fwd_ring<Tag, 64, 2, 2, 2, 0, 2>(p, l.mode, s);   // + row sums by v_dot2c on the packed weights (= the production plain kernel)
         case 86: return launch_fwd_ring<Tag, 64, 1, 3, 2, 0, 2>(p, l.mode, s);
         case 87: return launch_fwd_ring<Tag, 64, 1, 2, 1, 0, 2>(p, l.mode, s);
         case 50: return launch_fwd_split<Tag, 64, 2, 2>(p, l.mode, s);
@@ -80,12 +72,12 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 67: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 5>(p, l.mode, s);
         case 7: return launch_fwd_pipe_mode<Tag, 64, 2, 1, 1>(p, l.mode, s);
         case 8: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 1>(p, l.mode, s);
-        case 4: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 1, 2>(p, l.mode, s); break;
-        case 6: if (!gen) return launch_fwd_pipe_mode<Tag, 64, 2, 1>(p, l.mode, s); break;
-        case 9: if (!gen) return launch_fwd_pp_mode<Tag, 64, 2>(p, l.mode, s); break;
-        case 13: if (!gen) return launch_fwd_w8_mode<Tag, 64, 2, 2, 0>(p, l.mode, s); break;
-        case 15: if (!gen) return launch_fwd_w8_mode<Tag, 64, 1, 4, 0>(p, l.mode, s); break;
-        case 16: if (!gen) return launch_fwd_w8_mode<Tag, 64, 1, 4, 1>(p, l.mode, s); break;
+        case 4: return launch_fwd_pipe_mode<Tag, 64, 1, 2>(p, l.mode, s); break;
+        case 6: return launch_fwd_pipe_mode<Tag, 64, 2, 1>(p, l.mode, s); break;
+        case 9: return launch_fwd_pp_mode<Tag, 64, 2>(p, l.mode, s); break;
+        case 13: return launch_fwd_w8_mode<Tag, 64, 2, 2, 0>(p, l.mode, s); break;
+        case 15: return launch_fwd_w8_mode<Tag, 64, 1, 4, 0>(p, l.mode, s); break;
+        case 16: return launch_fwd_w8_mode<Tag, 64, 1, 4, 1>(p, l.mode, s); break;
         // ---- ablations (plain mode only; results are NOT attention outputs)
         case 21: return launch_fwd_abl<Tag, 64, 2, 2, 1>(p, s);
         case 23: return launch_fwd_abl<Tag, 64, 2, 2, 3>(p, s);
@@ -97,6 +89,23 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         default: break;
     }
     return launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);
+}
+#endif
+template <typename Tag>
+static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (p.drop_thr) return launch_fwd_drop<Tag, 64, 1, 2>(p, l.mode, s);
+    if (l.mode >= MODE_GENERAL && l.mode != MODE_KEYPAD) return launch_gen<Tag>(p, l, s);   // key-padding masks ride the plain tuning points
+    // auto (what ABI callers get), measured on MI355X at (8,16,4096,64), 200 launches each. All plain / causal / key-padding
+    // kernels run with seeded accumulators (Q pre-scaled, S starts at -m, row sums by v_dot2c on the packed weights):
+    //   plain : QB=2 / 2 waves per SIMD / direct-to-LDS  1058 TFLOP/s  (unseeded two-set ring 1005; QB=1 / 3 waves 983); 1130 with the loop unrolled by its buffers
+    //   causal: QB=1 / 3 waves per SIMD / direct-to-LDS   772 TFLOP/s  (unseeded 734; QB=2 719: coarser diagonal, worse tail)
+    const long blocks_qb2 = (long)((p.Sq + 255) / 256) * p.B * p.H;
+    const bool big_plain = (l.mode == MODE_PLAIN || (l.mode == MODE_KEYPAD && !p.causal)) && blocks_qb2 >= 512 && p.Sq >= 256;   // 512 = one full round of two workgroups per CU
+#ifdef FASN_DEV_VARIANTS
+    if (l.variant != 0) return dev_variant<Tag>(p, l, s);
+#endif
+    if (big_plain) return launch_fwd_cfg<Tag, 64, 2, 2, 4, 2, 2>(p, l.mode, s);
+    return launch_fwd_cfg<Tag, 64, 1, 3, 4, 2, 2>(p, l.mode, s);
 }
 int launch_fwd_d64(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     return l.dtype == 1 ? go<bf16_tag>(p, l, s) : go<f16_tag>(p, l, s);

@@ -13,12 +13,12 @@ int launch_splitk_one(FwdParams p, hipStream_t s) {
     constexpr int OCC = 2;
     constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2 + (MODE == MODE_GENERAL ? 4 * 6144 : 0);
     p.nqblk = (p.Sq + BM - 1) / BM;
-    auto kern = fasn_fwd_kernel<Tag, D, 1, MODE, OCC, 4, 0, 0, 0, RING, 1>;
-    set_smem_attr(kern, smem);
+    constexpr auto kern = &fasn_fwd_kernel<Tag, D, 1, MODE, OCC, 4, 0, 0, 0, RING, 1>;
+    ensure_smem<kern>(smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.nsplit * p.B * p.H)), dim3(256), smem, s, p);
     const int64_t nthr = (int64_t)p.B * p.H * p.Sq * (D / 4);
     hipLaunchKernelGGL((fasn_fwd_combine_kernel<Tag, D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -6;
+    return launch_rc();
 }
 template <typename Tag, int D>
 int launch_splitk_mode(const FwdParams& p, int mode, hipStream_t s) {

@@ -2,7 +2,8 @@
 //   y_i = exp(x_i - m) / (n * exp(-m) + sum_j exp(x_j - m)),  m = max(x) (and m >= 0 when n > 0 so that
 //   n * exp(-m) cannot overflow) — reference: flash_attention_softmax_n/core/functional.py:15-29.
 //   dx_i = y_i * (dy_i - sum_j dy_j y_j)   (n enters only through y).
-// One workgroup per row; the row is cached in registers when it fits (cols <= 256*EPT), fp32 math.
+// One workgroup per row at a time, rows taken in a grid-stride loop (the grid is capped: HIP rejects launches of 2^32 or more
+// threads, so rows >= 2^24 cannot have a workgroup each); the row is cached in registers when it fits (cols <= 256*EPT), fp32 math.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "fasn.h"
@@ -43,11 +44,12 @@ FASN_DEV float block_reduce(float v, float* red) {
 }
 
 constexpr int EPT = 16;  // cached elements per thread
+constexpr int64_t kMaxRowGrid = 1 << 20;  // workgroups per launch; more rows than that are walked by the grid-stride loop
 
 template <int DT>
-__global__ void __launch_bounds__(256) softmax_n_fwd_kernel(const void* x, void* y, int64_t cols, int64_t xs, int64_t ys, float n) {
+__global__ void __launch_bounds__(256) softmax_n_fwd_kernel(const void* x, void* y, int64_t rows, int64_t cols, int64_t xs, int64_t ys, float n) {
     __shared__ float red[4];
-    const int64_t row = blockIdx.x;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     const int64_t xo = row * xs, yo = row * ys;
     const bool cached = cols <= 256 * EPT;
     float v[EPT];
@@ -86,17 +88,19 @@ __global__ void __launch_bounds__(256) softmax_n_fwd_kernel(const void* x, void*
     } else {
         for (int64_t c = threadIdx.x; c < cols; c += 256) IO<DT>::st(y, yo + c, __expf(IO<DT>::ld(x, xo + c) - mx) * inv);
     }
+    }
 }
 
 template <int DT>
-__global__ void __launch_bounds__(256) softmax_n_bwd_kernel(const void* y, const void* dy, void* dx, int64_t cols, int64_t ys, int64_t dys, int64_t dxs) {
+__global__ void __launch_bounds__(256) softmax_n_bwd_kernel(const void* y, const void* dy, void* dx, int64_t rows, int64_t cols, int64_t ys, int64_t dys, int64_t dxs) {
     __shared__ float red[4];
-    const int64_t row = blockIdx.x;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     float dot = 0.f;
     for (int64_t c = threadIdx.x; c < cols; c += 256) dot += IO<DT>::ld(y, row * ys + c) * IO<DT>::ld(dy, row * dys + c);
     dot = block_reduce<false>(dot, red);
     for (int64_t c = threadIdx.x; c < cols; c += 256)
         IO<DT>::st(dx, row * dxs + c, IO<DT>::ld(y, row * ys + c) * (IO<DT>::ld(dy, row * dys + c) - dot));
+    }
 }
 
 }  // namespace fasn
@@ -109,11 +113,11 @@ int fasn_softmax_n_fwd(const void* x, void* y, int64_t rows, int64_t cols, int64
                        int32_t dtype, fasn_stream_t stream) {
     if (x == nullptr || y == nullptr || rows <= 0 || cols <= 0 || !(n >= 0.f)) return FASN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)rows);
+    const dim3 grid((unsigned)(rows < kMaxRowGrid ? rows : kMaxRowGrid));
     switch (dtype) {
-        case FASN_DTYPE_F16: hipLaunchKernelGGL(softmax_n_fwd_kernel<FASN_DTYPE_F16>, grid, dim3(256), 0, s, x, y, cols, x_row_stride, y_row_stride, n); break;
-        case FASN_DTYPE_BF16: hipLaunchKernelGGL(softmax_n_fwd_kernel<FASN_DTYPE_BF16>, grid, dim3(256), 0, s, x, y, cols, x_row_stride, y_row_stride, n); break;
-        case FASN_DTYPE_F32: hipLaunchKernelGGL(softmax_n_fwd_kernel<FASN_DTYPE_F32>, grid, dim3(256), 0, s, x, y, cols, x_row_stride, y_row_stride, n); break;
+        case FASN_DTYPE_F16: hipLaunchKernelGGL(softmax_n_fwd_kernel<FASN_DTYPE_F16>, grid, dim3(256), 0, s, x, y, rows, cols, x_row_stride, y_row_stride, n); break;
+        case FASN_DTYPE_BF16: hipLaunchKernelGGL(softmax_n_fwd_kernel<FASN_DTYPE_BF16>, grid, dim3(256), 0, s, x, y, rows, cols, x_row_stride, y_row_stride, n); break;
+        case FASN_DTYPE_F32: hipLaunchKernelGGL(softmax_n_fwd_kernel<FASN_DTYPE_F32>, grid, dim3(256), 0, s, x, y, rows, cols, x_row_stride, y_row_stride, n); break;
         default: return FASN_EDTYPE;
     }
     return hipGetLastError() == hipSuccess ? FASN_OK : FASN_ELAUNCH;
@@ -123,11 +127,11 @@ int fasn_softmax_n_bwd(const void* y, const void* dy, void* dx, int64_t rows, in
                        int64_t dx_row_stride, int32_t dtype, fasn_stream_t stream) {
     if (y == nullptr || dy == nullptr || dx == nullptr || rows <= 0 || cols <= 0) return FASN_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)rows);
+    const dim3 grid((unsigned)(rows < kMaxRowGrid ? rows : kMaxRowGrid));
     switch (dtype) {
-        case FASN_DTYPE_F16: hipLaunchKernelGGL(softmax_n_bwd_kernel<FASN_DTYPE_F16>, grid, dim3(256), 0, s, y, dy, dx, cols, y_row_stride, dy_row_stride, dx_row_stride); break;
-        case FASN_DTYPE_BF16: hipLaunchKernelGGL(softmax_n_bwd_kernel<FASN_DTYPE_BF16>, grid, dim3(256), 0, s, y, dy, dx, cols, y_row_stride, dy_row_stride, dx_row_stride); break;
-        case FASN_DTYPE_F32: hipLaunchKernelGGL(softmax_n_bwd_kernel<FASN_DTYPE_F32>, grid, dim3(256), 0, s, y, dy, dx, cols, y_row_stride, dy_row_stride, dx_row_stride); break;
+        case FASN_DTYPE_F16: hipLaunchKernelGGL(softmax_n_bwd_kernel<FASN_DTYPE_F16>, grid, dim3(256), 0, s, y, dy, dx, rows, cols, y_row_stride, dy_row_stride, dx_row_stride); break;
+        case FASN_DTYPE_BF16: hipLaunchKernelGGL(softmax_n_bwd_kernel<FASN_DTYPE_BF16>, grid, dim3(256), 0, s, y, dy, dx, rows, cols, y_row_stride, dy_row_stride, dx_row_stride); break;
+        case FASN_DTYPE_F32: hipLaunchKernelGGL(softmax_n_bwd_kernel<FASN_DTYPE_F32>, grid, dim3(256), 0, s, y, dy, dx, rows, cols, y_row_stride, dy_row_stride, dx_row_stride); break;
         default: return FASN_EDTYPE;
     }
     return hipGetLastError() == hipSuccess ? FASN_OK : FASN_ELAUNCH;

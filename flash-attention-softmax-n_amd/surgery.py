@@ -31,12 +31,13 @@ HF_ATTENTION_NAME = "softmax_n_hip"   # key under which the attention function i
 __all__ = ["PolicyRegistry", "policy_registry", "apply_attention_softmax_n", "register_hf_attention", "HF_ATTENTION_NAME"]
 
 
+
 class PolicyRegistry(Dict[Type[Module], AttentionSoftmaxNReplacementFunction]):
     """module class -> surgery function (reference surgery_functions/utils.py:12-93)."""
 
     def register(self, *modules: Type[Module]):
         if len(modules) == 0:
-            raise ValueError("Registry decoration without any module class inputs has no effect.")
+            raise ValueError("register() needs at least one torch.nn.Module class to attach the surgery function to")
 
         def check_signature(func: Callable) -> None:
             params = list(inspect.signature(func).parameters.items())
@@ -128,10 +129,12 @@ def _hf_attention(module: Module, query: torch.Tensor, key: torch.Tensor, value:
     ([B,1,L,S], finfo.min where hidden) is passed as `attn_bias` through its broadcast strides."""
     from .flash_attn import flash_attention_n
     n = float(getattr(module, "softmax_n_param", 0.0))
+    if kwargs.get("head_mask") is not None:
+        raise NotImplementedError("head_mask multiplies the attention probabilities, which the fused kernel never materialises")
     bias = mask = None
     if attention_mask is not None:
         if attention_mask.dtype == torch.bool:
-            mask = attention_mask
+            mask = attention_mask[..., : key.shape[-2]]   # row stride 0 (from _hf_mask) -> the key-padding kernels
         else:
             bias = attention_mask[..., : key.shape[-2]]
             keymask = _as_key_padding_mask(bias)
@@ -142,28 +145,40 @@ def _hf_attention(module: Module, query: torch.Tensor, key: torch.Tensor, value:
     return out.transpose(1, 2).contiguous(), None
 
 
-_KEYMASK_CACHE = {"key": None, "value": None}
-
-
 def _as_key_padding_mask(additive: torch.Tensor) -> Optional[torch.Tensor]:
-    """HF models hand every attention layer the same additive mask, [B,1,1,S] with 0 for real tokens and a huge negative
-    number for padding. If `additive` is exactly that (row-broadcast, only 0 and values <= -1e4), return the equivalent boolean
-    key mask, else None. The check costs one device synchronisation, so its result is cached per mask tensor: one sync per
-    forward pass, not per layer."""
+    """Older `transformers` versions (and direct callers) hand every layer an ADDITIVE mask, [B,1,1,S] (or a row-broadcast
+    expansion of it) with 0 for real tokens and a huge negative number for padding. A row-broadcast additive mask is turned
+    into the boolean key mask `additive > -1e4` WITHOUT inspecting its values (no device synchronisation, nothing cached -
+    a cache keyed on the tensor's address would return a previous batch's mask once the allocator reuses the address):
+    entries above the threshold attend, entries at or below it (finfo.min, -inf, -1e9, -1e4) are hidden. A row-broadcast
+    mask whose finite entries are not 0 is not a padding mask; it keeps its additive meaning because the caller only takes
+    this route for masks that `_hf_mask` / HF's `get_extended_attention_mask` build, which are 0 / min by construction.
+    Anything with a real row dimension (e.g. causal) returns None and stays an additive bias."""
     if additive.dim() != 4 or additive.shape[1] != 1:
         return None
     if additive.shape[-2] != 1:
-        if additive.stride(-2) != 0:      # a real [.., L, S] mask (e.g. causal): not a key-padding mask
+        if additive.stride(-2) != 0:
             return None
         additive = additive[..., :1, :]   # expanded view of a row-broadcast mask
-    key = (additive.data_ptr(), tuple(additive.shape), additive._version, additive.dtype)
-    if _KEYMASK_CACHE["key"] == key:
-        return _KEYMASK_CACHE["value"]
-    visible = additive == 0
-    binary = bool((visible | (additive <= -1e4)).all().item())
-    value = visible if binary else None
-    _KEYMASK_CACHE["key"], _KEYMASK_CACHE["value"] = key, value
-    return value
+    return additive > -1e4
+
+
+def _hf_mask(batch_size: int, q_length: int, kv_length: int, q_offset: int = 0, kv_offset: int = 0, mask_function=None,
+             attention_mask: Optional[torch.Tensor] = None, **kwargs):
+    """`transformers.AttentionMaskInterface` function for HF_ATTENTION_NAME. Without a registered mask function transformers
+    hands a custom attention function `attention_mask=None` - every layer would silently attend to padding tokens.
+    Bidirectional models with a 2-D padding mask get it back as a boolean [B,1,L,S] view with ROW STRIDE 0 (True = attend),
+    which is exactly the kernels' key-padding form (one byte per key, padded tiles skipped); everything else (causal,
+    sliding window, packed sequences, or/and-mask functions) is built by transformers' own boolean `sdpa_mask`."""
+    from transformers import masking_utils as mu
+    if (attention_mask is not None and attention_mask.dim() == 2 and mask_function is getattr(mu, "bidirectional_mask_function", object())
+            and attention_mask.shape[-1] >= kv_offset + kv_length):
+        keys = attention_mask[:, kv_offset:kv_offset + kv_length].to(torch.bool)
+        return keys[:, None, None, :].expand(batch_size, 1, q_length, kv_length)
+    kwargs.pop("allow_is_bidirectional_skip", None)
+    # never "skip" to None for a padded batch; an all-True mask may still come back as None, which means "no mask"
+    return mu.sdpa_mask(batch_size=batch_size, q_length=q_length, kv_length=kv_length, q_offset=q_offset, kv_offset=kv_offset,
+                        mask_function=mask_function, attention_mask=attention_mask, **kwargs)
 
 
 def register_hf_attention() -> bool:
@@ -175,6 +190,12 @@ def register_hf_attention() -> bool:
         return False
     if HF_ATTENTION_NAME not in AttentionInterface._global_mapping:
         AttentionInterface.register(HF_ATTENTION_NAME, _hf_attention)
+    try:   # the padding mask only reaches a custom attention function whose name also has a mask function
+        from transformers import AttentionMaskInterface
+        if HF_ATTENTION_NAME not in AttentionMaskInterface._global_mapping:
+            AttentionMaskInterface.register(HF_ATTENTION_NAME, _hf_mask)
+    except ImportError:   # transformers 4.48 - 4.52: the model builds the additive mask itself and passes it on
+        pass
     classes = []
     for mod_name, cls_names in (("transformers.models.bert.modeling_bert", ("BertSelfAttention", "BertCrossAttention")),
                                 ("transformers.models.roberta.modeling_roberta", ("RobertaSelfAttention", "RobertaCrossAttention"))):
@@ -208,7 +229,8 @@ def hf_self_attention_surgery(module: Module, module_index: int, softmax_n_param
 
 
 # ------------------------------------------------------------------------------------------------------------ XLNet
-def _xlnet_rel_attn_core(self, q_head, k_head_h, v_head_h, k_head_r, seg_mat=None, attn_mask=None, output_attentions=False):
+def _xlnet_rel_attn_core(self, q_head, k_head_h, v_head_h, k_head_r, seg_mat=None, attn_mask=None, head_mask=None,
+                         output_attentions=False, **kwargs):
     """Replacement for `XLNetRelativeAttention.rel_attn_core` (same arguments and return value; tensors are [len, batch,
     head, dim]). Position (bd) and segment (ef) scores are computed as the module always did and enter one fused
     `flash_attention_n` call as the additive bias; the content score, softmax_n, dropout and the weighted sum happen in the
@@ -227,12 +249,18 @@ def _xlnet_rel_attn_core(self, q_head, k_head_h, v_head_h, k_head_r, seg_mat=Non
     visible = None
     if attn_mask is not None:          # [i, j, b, n] (n may be 1), 1 = masked
         visible = torch.einsum("ijbn->bnij", attn_mask) == 0
-    if output_attentions:
+    if output_attentions or head_mask is not None:
+        # the probabilities themselves are wanted (or multiplied by head_mask, as transformers 4.x passes it and the reference's
+        # rel_attn_core applies it, surgery_functions/_xlnet.py:66-67): the module's einsum route with the softmax_n row kernel
         ac = torch.einsum("ibnd,jbnd->bnij", q_head + self.r_w_bias, k_head_h)
         score = (ac + extra) * self.scale
         if visible is not None:
             score = score.masked_fill(~visible, float("-inf"))
         prob = self.dropout(softmax_n(score, n=n, dim=3))
+        if head_mask is not None:
+            prob = prob * torch.einsum("ijbn->bnij", head_mask)
+        if not output_attentions:
+            return torch.einsum("bnij,jbnd->ibnd", prob, v_head_h)
         return torch.einsum("bnij,jbnd->ibnd", prob, v_head_h), torch.einsum("bnij->ijbn", prob)
     q = (q_head + self.r_w_bias).permute(1, 2, 0, 3)      # [b, n, i, d]
     k = k_head_h.permute(1, 2, 0, 3)

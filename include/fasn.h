@@ -153,13 +153,6 @@ int fasn_softmax_n_bwd(const void* y, const void* dy, void* dx, int64_t rows, in
 int fasn_moments(const void* x, double* sums, int64_t rows, int64_t cols, int64_t row_stride, int32_t dtype,
                  fasn_stream_t stream);
 
-/* Timing helper for bench.py: elapsed milliseconds between two events recorded on `stream`
- * around `iters` back-to-back forward launches (HIP events on the launch stream). */
-int fasn_time_fwd(const fasn_fwd_args* args, fasn_stream_t stream, int32_t warmup, int32_t iters,
-                  float* ms_per_iter);
-int fasn_time_bwd(const fasn_bwd_args* args, fasn_stream_t stream, int32_t warmup, int32_t iters,
-                  float* ms_per_iter);
-
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,10 @@ Fixtures:
                    reference slow_attention_n on 4 (b,h) x 64 sampled rows, native dtype and fp32-upcast.
   g5_<cfg>.npz     backward: one full (b,h) slice through slow_attention_n + autograd (fp32 upcast) with generated dO;
                    64 sampled rows of dQ, dK, dV.
+  g5f_<cfg>.npz    backward at the FULL sequence length of every BASELINE config (C2, C3, M0, C4 with ALiBi + key padding at
+                   S = 8192, C5): three (b,h) heads each through slow_attention_n + autograd, once in fp32 (the "true" answer)
+                   and once in the config's NATIVE dtype (what the reference's own GPU test compares against,
+                   tests/gpu/core/test_flash_attn.py:29-48); 64 sampled rows of O, dQ, dK, dV per head.
 """
 import importlib.util
 import os
@@ -161,6 +165,38 @@ def g5(cfg, S_override=None):
          checksums=np.array([synth.checksum(q), synth.checksum(k), synth.checksum(v), synth.checksum(do)], dtype=np.int64))
 
 
+def g5f(cfg):
+    """full-S backward rows of three heads; the GPU test runs the whole (B,H,S,D) grid and compares these heads"""
+    B, H, S, D, dtype, n, causal, extra = CONFIGS[cfg]
+    heads = [(0, 0), (B - 1, H // 2), (B // 2, H - 1)]
+    rng = np.random.RandomState({"c2": 12, "c3": 13, "m0": 10, "c4": 14, "c5": 15}[cfg])
+    rows = np.sort(np.concatenate([[0, S - 1], rng.choice(np.arange(1, S - 1), 62, replace=False)])).astype(np.int64)
+    out = {k_: [] for k_ in ("o", "dq", "dk", "dv", "o_native", "dq_native", "dk_native", "dv_native")}
+    cks = []
+    for (b, h) in heads:
+        q, k, v, do = (head_slice(nm, B, H, S, D, dtype, b, h) for nm in ("q", "k", "v", "dout"))
+        cks.append([synth.checksum(t) for t in (q, k, v, do)])
+        add = None
+        if extra == "alibi+keypad":
+            add = synth.alibi_bias_rows(H, S, S, [h], np.arange(S), dtype)[0].float()
+            keep = synth.keypad_mask(B, S)[b, 0, 0]
+            add = add.masked_fill(~keep.unsqueeze(0), float("-inf"))
+        if causal:
+            add = torch.zeros(S, S, dtype=torch.float32) if add is None else add
+            add = add.masked_fill(torch.arange(S).unsqueeze(0) > torch.arange(S).unsqueeze(-1), float("-inf"))
+        for tag, dt in (("", torch.float32), ("_native", dtype)):
+            qq, kk, vv = (t.to(dt).requires_grad_() for t in (q, k, v))
+            o = slow_attention_n(qq, kk, vv, attn_mask=None if add is None else add.to(dt), softmax_n_param=n)
+            o.backward(do.to(dt))
+            out["o" + tag].append(o.detach().float().numpy()[rows])
+            out["dq" + tag].append(qq.grad.float().numpy()[rows])
+            out["dk" + tag].append(kk.grad.float().numpy()[rows])
+            out["dv" + tag].append(vv.grad.float().numpy()[rows])
+            del o, qq, kk, vv
+    save(f"g5f_{cfg}.npz", heads=np.array(heads), rows=rows, shape=np.array([B, H, S, D]), n=np.float64(n), causal=np.int64(causal),
+         checksums=np.array(cks, dtype=np.int64), **{k_: np.stack(v_) for k_, v_ in out.items()})
+
+
 def g6():
     spec_s = importlib.util.spec_from_file_location("ref_statistics", "/root/reference/flash_attention_softmax_n/analysis/statistics.py")
     st = importlib.util.module_from_spec(spec_s)
@@ -191,6 +227,10 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["g6"]:
         g6()
         sys.exit(0)
+    if sys.argv[1:2] == ["g5f"]:
+        for c in (sys.argv[2:] or list(CONFIGS)):
+            g5f(c)
+        sys.exit(0)
     g1()
     g3()
     for c in CONFIGS:
@@ -198,4 +238,6 @@ if __name__ == "__main__":
     for c in ("c2", "c3", "m0"):
         g5(c)
     g5("c4", S_override=2048)
+    for c in CONFIGS:
+        g5f(c)
     g6()

@@ -25,6 +25,17 @@ def test_library_exports_every_header_symbol(pkg):
     assert set(pkg._lib.EXPORTS) == set(names)
 
 
+def test_library_exports_nothing_but_the_header(pkg):
+    """`nm -D libfasn.so`: the defined fasn_* symbols are exactly the header's functions — no developer entry points
+    (fasn_fwd_variant, timing helpers), and the library reads no environment variable."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg._lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("fasn_") and l.split()[-2] in "TtWw"})
+    assert exported == _header_functions(), exported
+    und = subprocess.run(["nm", "-D", "--undefined-only", pkg._lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "getenv" not in und
+
+
 def test_abi_version_and_strerror(pkg):
     lib = pkg._lib.load()
     assert lib.fasn_abi_version() == 2

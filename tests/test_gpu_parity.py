@@ -59,6 +59,13 @@ def test_flash_attention_n_vs_oracle(pkg, dev, n, scale, is_causal, dtype):
     _check(q.grad, dq, dtype, "dq")
     _check(k.grad, dk, dtype, "dk")
     _check(v.grad, dv, dtype, "dv")
+    # the reference test's literal criterion: atol vs slow_attention_n run in the NATIVE dtype, rtol 0, gradients included
+    qn, kn, vn = (t.detach().cpu().requires_grad_() for t in (q, k, v))
+    on = ref_attention_n(qn, kn, vn, softmax_n_param=float(n), scale=scale, is_causal=is_causal)
+    on.backward(do.cpu())
+    for what, got, want in (("out", out, on), ("dq", q.grad, qn.grad), ("dk", k.grad, kn.grad), ("dv", v.grad, vn.grad)):
+        err = (got.detach().float().cpu() - want.detach().float()).abs().max().item()
+        assert err <= REF_ATOL[dtype], f"{what}: max-abs {err:.3e} vs native-dtype oracle > literal atol {REF_ATOL[dtype]}"
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -161,6 +168,39 @@ def test_golden_g5_backward_rows(pkg, dev, golden_dir, cfg):
     _check(q.grad[0, 0][rows], torch.from_numpy(g["dq"]), dtype, "dq")
     _check(k.grad[0, 0][rows], torch.from_numpy(g["dk"]), dtype, "dk")
     _check(v.grad[0, 0][rows], torch.from_numpy(g["dv"]), dtype, "dv")
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "m0", "c5", "c4"])
+def test_golden_g5f_backward_at_full_grid(pkg, dev, golden_dir, cfg):
+    """Forward + backward of every BASELINE config at its FULL (B,H,S,D) grid (C4: dense ALiBi [H,L,S] + key padding, S = 8192,
+    D = 128; C5: B = 64); sampled rows of O, dQ, dK, dV of three (b,h) heads against the real reference's slow_attention_n +
+    autograd. Two gates per tensor: the reference test's literal criterion (tests/gpu/core/test_flash_attn.py:14,46-48: atol
+    1e-2 fp16 / 5e-2 bf16, rtol 0, against slow_attention_n in the NATIVE dtype) and a relative gate against the fp32 answer."""
+    g = np.load(os.path.join(golden_dir, f"g5f_{cfg}.npz"))
+    dtype = G4[cfg]
+    B, H, S, D = (int(x) for x in g["shape"])
+    n, causal = float(g["n"]), bool(g["causal"])
+    q, k, v, do = (_full(nm, (B, H, S, D), dtype, dev) for nm in ("q", "k", "v", "dout"))
+    for hi, (b, h) in enumerate(g["heads"]):
+        assert [synth.checksum(t[int(b), int(h)]) for t in (q, k, v, do)] == list(g["checksums"][hi])
+    bias = mask = None
+    if cfg == "c4":
+        bias = synth.alibi_bias(H, S, S, dtype, device=dev)
+        mask = synth.keypad_mask(B, S, device=dev)
+    q.requires_grad_(), k.requires_grad_(), v.requires_grad_()
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal, attn_mask=mask, attn_bias=bias)
+    out.backward(do)
+    rows = torch.from_numpy(g["rows"]).to(dev)
+    for hi, (b, h) in enumerate(g["heads"]):
+        for name, t in (("o", out), ("dq", q.grad), ("dk", k.grad), ("dv", v.grad)):
+            got = t[int(b), int(h)][rows].detach().float().cpu()
+            true, native = torch.from_numpy(g[name][hi]), torch.from_numpy(g[name + "_native"][hi])
+            assert torch.isfinite(got).all()
+            lit = (got - native).abs().max().item()
+            assert lit <= REF_ATOL[dtype], f"{cfg} head {hi} {name}: max-abs {lit:.3e} vs native slow_attention_n > atol {REF_ATOL[dtype]}"
+            err = (got - true).abs().max().item()
+            lim = REL_TRUE[dtype] * max(true.abs().max().item(), 1e-2)
+            assert err <= lim, f"{cfg} head {hi} {name}: max-abs {err:.3e} vs fp32 slow_attention_n > {lim:.3e}"
 
 
 # ---------------------------------------------------------------- masks, bias, layouts, edge cases

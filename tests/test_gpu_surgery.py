@@ -32,6 +32,12 @@ def test_bert_with_softmax_n_attention(pkg, dev, n, dtype):
         pytest.skip("transformers without AttentionInterface")
     if "oracle_softmax_n" not in AttentionInterface._global_mapping:
         AttentionInterface.register("oracle_softmax_n", _oracle_attention)
+        try:   # without a mask function transformers passes attention_mask=None to a custom attention name
+            from transformers import AttentionMaskInterface
+            from transformers.masking_utils import eager_mask
+            AttentionMaskInterface.register("oracle_softmax_n", eager_mask)
+        except ImportError:
+            pass
     torch.manual_seed(0)
     cfg = BertConfig(vocab_size=100, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                      max_position_embeddings=160, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
@@ -48,6 +54,15 @@ def test_bert_with_softmax_n_attention(pkg, dev, n, dtype):
     model.config._attn_implementation = "oracle_softmax_n"
     with torch.no_grad():
         want = model(input_ids=ids, attention_mask=att).last_hidden_state.float()
+
+    if n == 0.0:   # softmax_0 = the model's own attention: the oracle route itself must honour the padding mask
+        model.config._attn_implementation = "eager"
+        with torch.no_grad():
+            own = model(input_ids=ids, attention_mask=att).last_hidden_state.float()
+        assert ((own - want) * att.bool().unsqueeze(-1)).abs().max().item() <= 4 * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * want.abs().max().item()
+        with torch.no_grad():
+            nomask = model(input_ids=ids).last_hidden_state.float()
+        assert ((nomask - want) * att.bool().unsqueeze(-1)).abs().max().item() > 0.05   # padding matters in this batch
 
     count = surgery.apply_attention_softmax_n(model, softmax_n_param=n)
     assert count == cfg.num_hidden_layers

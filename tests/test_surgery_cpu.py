@@ -147,3 +147,63 @@ def test_hf_policy_registration_is_idempotent(clean_registry):
     assert policy_registry[BertSelfAttention] is surgery.hf_self_attention_surgery
     from transformers.models.xlnet.modeling_xlnet import XLNetRelativeAttention
     assert policy_registry[XLNetRelativeAttention] is surgery.xlnet_relative_attention_surgery
+
+
+def test_padding_mask_reaches_the_attention_function_after_surgery(clean_registry, monkeypatch):
+    """A padded batch through a surgically converted BERT (CPU plumbing test: the kernel call is replaced by the oracle):
+    the attention function must RECEIVE the padding mask (transformers hands `None` to a custom attention name that has no
+    mask function registered - every layer would then attend to padding), as a boolean row-broadcast [B,1,L,S] view, and with
+    n = 0 the converted model must reproduce the model's own eager attention on the real tokens."""
+    pytest.importorskip("transformers")
+    if not surgery.register_hf_attention():
+        pytest.skip("transformers without AttentionInterface")
+    from transformers import BertConfig, BertModel
+    import flash_attention_softmax_n_amd.flash_attn as fa
+    seen = []
+
+    def oracle_flash(query, key, value, softmax_n_param=None, scale=None, dropout_p=0.0, attn_mask=None, attn_bias=None, is_causal=False):
+        seen.append(attn_mask)
+        return ref_attention_n(query, key, value, softmax_n_param=softmax_n_param, scale=scale, attn_mask=attn_mask, attn_bias=attn_bias,
+                               is_causal=is_causal)
+
+    monkeypatch.setattr(fa, "flash_attention_n", oracle_flash)
+    torch.manual_seed(0)
+    cfg = BertConfig(vocab_size=100, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                     max_position_embeddings=40, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = BertModel(cfg, add_pooling_layer=False).eval()
+    model.config._attn_implementation = "eager"
+    ids = torch.randint(0, 100, (3, 20))
+    att = torch.ones(3, 20, dtype=torch.long)
+    att[1, 10:] = 0
+    att[2, 3:] = 0
+    with torch.no_grad():
+        want = model(input_ids=ids, attention_mask=att).last_hidden_state
+    assert apply_attention_softmax_n(model, softmax_n_param=0.0) == cfg.num_hidden_layers
+    with torch.no_grad():
+        got = model(input_ids=ids, attention_mask=att).last_hidden_state
+    assert len(seen) == cfg.num_hidden_layers
+    for m in seen:
+        assert m is not None and m.dtype == torch.bool and m.shape == (3, 1, 20, 20)
+        assert m.stride(2) == 0                      # row-broadcast: the kernels' key-padding form
+        assert torch.equal(m[:, 0, 0], att.bool())
+    valid = att.bool().unsqueeze(-1)
+    assert ((got - want) * valid).abs().max().item() < 1e-5
+    # and the padded positions of sequence 1 DO differ from an unmasked run (the mask is really applied)
+    with torch.no_grad():
+        unmasked = model(input_ids=ids).last_hidden_state
+    assert ((unmasked - got) * valid).abs().max().item() > 1e-3
+
+
+def test_additive_padding_masks_are_converted_without_a_cache():
+    """the float-mask route (transformers 4.48+, direct callers): successive batches whose masks happen to live at the same
+    address must each get their own key mask (a pointer-keyed cache returned the previous batch's mask)"""
+    counts = []
+    for valid in (60, 70, 50, 64, 33):
+        add = torch.zeros(2, 1, 1, 80)
+        add[:, :, :, valid:] = torch.finfo(torch.float32).min
+        km = surgery._as_key_padding_mask(add.expand(2, 1, 16, 80))
+        counts.append(int(km[0].sum()))
+        del add
+    assert counts == [60, 70, 50, 64, 33]
+    assert surgery._as_key_padding_mask(torch.zeros(2, 1, 16, 80)) is None      # a real row dimension: stays a bias
+    assert surgery._as_key_padding_mask(torch.zeros(2, 4, 1, 80)) is None       # per-head: not HF's padding mask
