@@ -125,8 +125,12 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
         l.mode = !vec ? MODE_GENERAL_SLOW : (a->bias.ptr && a->mask.ptr) ? MODE_GENERAL : a->bias.ptr ? MODE_GENERAL_B : MODE_GENERAL_M;
         // key-padding mask (one byte per key for the whole (b,h), no bias): plain kernels + a per-tile visibility word
         if (a->mask.ptr && !a->bias.ptr && a->mask.stride[2] == 0 && a->mask.stride[3] == 1) {
-            p.keypad_fallback = l.mode;   // what the backward (and split-K) use until they have their own key-padding path
+            p.keypad_fallback = l.mode;   // what split-K and the fp32 kernels use: they have no key-padding path of their own
             l.mode = MODE_KEYPAD;
+        } else if (a->mask.ptr && a->bias.ptr && p.bias_vec && a->mask.stride[2] == 0 && a->mask.stride[3] == 1 && a->dtype != FASN_DTYPE_F32) {
+            // vector bias + key-padding mask (ALiBi on a padded batch): bias through the vector path, mask as visibility bits
+            p.keypad_fallback = l.mode;   // dropout and split-K instantiations take the dense-mask general mode instead
+            l.mode = MODE_BIAS_KEYPAD;
         }
     } else {
         l.mode = a->causal ? MODE_CAUSAL : MODE_PLAIN;
@@ -147,7 +151,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
 int plan_splitk(const fasn_fwd_args* a, const FwdParams& p, const FwdLaunch& l, int& tps) {
     tps = 0;
     if (l.dtype == FASN_DTYPE_F32 || p.drop_thr || l.mode == MODE_GENERAL_SLOW) return 1;
-    if (l.mode == MODE_KEYPAD && p.keypad_fallback == MODE_GENERAL_SLOW) return 1;
+    if ((l.mode == MODE_KEYPAD || l.mode == MODE_BIAS_KEYPAD) && p.keypad_fallback == MODE_GENERAL_SLOW) return 1;
     const int64_t base_blocks = (int64_t)a->B * a->H * ((a->Sq + 127) / 128);
     int ntiles = (a->Sk + KT - 1) / KT;
     if (a->causal) {   // the last row's visible keys bound the walk

@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 
     int bh, qi;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
-    const bool causal = (MODE == MODE_CAUSAL) || ((MODE == MODE_GENERAL || MODE == MODE_GENERAL_SLOW || MODE == MODE_KEYPAD) && p.causal);
+    const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
     const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * BM;
@@ -208,8 +208,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase), 0, p.kbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase), 0, p.vbytes, 0x00020000);
     TileStage<D, NLD> tsK, tsV;
-    tsK.init(tid, p.ks[2], MODE == MODE_GENERAL);
-    tsV.init(tid, p.vs[2], MODE == MODE_GENERAL);
+    tsK.init(tid, p.ks[2], mode_is_vector(MODE));
+    tsV.init(tid, p.vs[2], mode_is_vector(MODE));
     // K/V tiles go straight to LDS (`buffer_load ... lds`, one tile ahead): no staging registers and no ds_write instructions.
     // At D = 128 the S / dP accumulators would not fit next to staging registers (the compiler parks them in AGPRs and pays ~130
     // v_accvgpr moves per tile); at D = 64 it is worth 2 % of the backward (same-box A/B 1.845 -> 1.78 ms with the dK/dV kernel).
@@ -219,8 +219,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     const u32x4 krw = make_rsrc_words(kbase, p.kbytes), vrw = make_rsrc_words(vbase, p.vbytes);
     const uint32_t ldsK_w = lds_addr(ldsK) + wave * 1024, ldsV_w = lds_addr(ldsV) + wave * 1024;
     if (DIRECT) {
-        tdK.init(tid, p.ks[2], MODE == MODE_GENERAL);
-        tdV.init(tid, p.vs[2], MODE == MODE_GENERAL);
+        tdK.init(tid, p.ks[2], mode_is_vector(MODE));
+        tdV.init(tid, p.vs[2], mode_is_vector(MODE));
     }
     if (ntiles > 0) {
         if (DIRECT) {
@@ -251,9 +251,11 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     // subtracted, so those instantiations only seed S; the element-load kernels (MODE_GENERAL_SLOW) keep the unseeded arithmetic.
     // Each splat costs 16 registers per query block: where the kernel is at its register limit only one (or none) is used
     // (DQ_SEED: bit 0 = S, bit 1 = dP; the vector general mode builds its S start value per element and always seeds S).
-    constexpr bool SEED_S = MODE != MODE_GENERAL_SLOW && (MODE == MODE_GENERAL || (DQ_SEED & 1));
+    constexpr bool VEC = mode_is_vector(MODE);      // instantiated: MODE_GENERAL (bias and/or mask images) and MODE_BIAS_KEYPAD (bias image + visibility bits)
+    constexpr bool VMASK = mode_has_vmask(MODE);
+    constexpr bool SEED_S = MODE != MODE_GENERAL_SLOW && (VEC || (DQ_SEED & 1));
     constexpr bool SEED_P = MODE != MODE_GENERAL_SLOW && !DROP && (DQ_SEED & 2);
-    f32x16 sseed[(SEED_S && MODE != MODE_GENERAL) ? QB : 1], dseed[SEED_P ? QB : 1];
+    f32x16 sseed[(SEED_S && !VEC) ? QB : 1], dseed[SEED_P ? QB : 1];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         if (SEED_S) {
@@ -269,7 +271,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (SEED_S && MODE != MODE_GENERAL) sseed[qb][r] = -lse2[qb];
+            if (SEED_S && !VEC) sseed[qb][r] = -lse2[qb];
             if (SEED_P) dseed[qb][r] = -dlt[qb];
         }
     }
@@ -279,10 +281,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     // HBM -> LDS with coalesced `buffer_load ... lds` and is read back 32 / 16 bytes per lane; the additive term
     // (bias*log2e/c, or -inf where the mask byte is clear) is the S accumulator's start value. An absent operand gets a
     // zero-range descriptor (bias reads 0) / an all-ones OR word (mask keeps everything).
-    constexpr bool VEC = MODE == MODE_GENERAL;
     u32x4 brw, mrw;
     unsigned bvo[QB][4], mvo[QB][2];
-    const uint32_t nomask = (VEC && p.mask == nullptr) ? 0x01010101u : 0u;
+    const uint32_t nomask = (VMASK && p.mask == nullptr) ? 0x01010101u : 0u;
     const float binv = VEC ? kLog2e : 0.f;   // Q is pre-scaled: S' = bias*log2e - LSE*log2e + q'.k
     char* const ldsGB = smem + 4 * TILEB + wave * (QB * 6144);
     char* const ldsGM = ldsGB + QB * 4096;
@@ -292,15 +293,17 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) lds_dma16(brw, __builtin_amdgcn_readfirstlane(ldsGB_a + qb * 4096 + i * 1024), bvo[qb][i], t * (KT * 2));
+            if (VMASK) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) lds_dma16(mrw, __builtin_amdgcn_readfirstlane(ldsGM_a + qb * 2048 + i * 1024), mvo[qb][i], t * KT);
+                for (int i = 0; i < 2; ++i) lds_dma16(mrw, __builtin_amdgcn_readfirstlane(ldsGM_a + qb * 2048 + i * 1024), mvo[qb][i], t * KT);
+            }
         }
     };
     if (VEC) {
         const char* bb = p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
-        const char* mb = p.mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
+        const char* mb = (VMASK && p.mask) ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
         brw = make_rsrc_words(bb, p.bias ? p.bias_bytes : 0u);
-        mrw = make_rsrc_words(mb, p.mask ? p.mask_bytes : 0u);
+        mrw = make_rsrc_words(mb, (VMASK && p.mask) ? p.mask_bytes : 0u);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 
     // MODE_KEYPAD (mask = one byte per key of the (b,h), no bias), as in the forward: each lane fetches the byte of key
     // k0 + lane one tile ahead, a ballot makes the tile's visibility word; all-visible tiles are plain, all-hidden ones skipped
-    constexpr bool KP = MODE == MODE_KEYPAD;
+    constexpr bool KP = mode_has_keypad(MODE);
     __amdgpu_buffer_rsrc_t kprs;
     uint32_t kp_next = 0;
     if (KP) {
@@ -338,14 +341,18 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         const int buf = FASN_BWD_UNROLL2 ? decltype(BUF_)::value : (t & 1);
         const int k0 = t * KT;
         uint64_t kp_bits = ~0ull;
-        if (KP) {
+        if (KP && !VEC) {
             kp_bits = __ballot(kp_next != 0);
             kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
         }
         uint32_t mraw[QB][2][4];
         u32x2 braw[QB][2][4];
         if (VEC) {   // unconditional, also for skipped tiles: the request / wait pattern is the same for every tile
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's image has landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's image (and its visibility bytes) have landed
+            if (KP) {   // the next tile's bytes are requested after the wait, so it does not cover their latency
+                kp_bits = __ballot(kp_next != 0);
+                kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
+            }
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -356,9 +363,11 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                         braw[qb][kb][2 * j] = u32x2{w[0], w[1]};
                         braw[qb][kb][2 * j + 1] = u32x2{w[2], w[3]};
                     }
-                    const u32x4 w = *LDS_PTR(const u32x4, ldsGM + qb * 2048 + tile_off<32>(l31, kb * 2 + hi));
+                    if (VMASK) {
+                        const u32x4 w = *LDS_PTR(const u32x4, ldsGM + qb * 2048 + tile_off<32>(l31, kb * 2 + hi));
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) mraw[qb][kb][g] = w[g] | nomask;
+                        for (int g = 0; g < 4; ++g) mraw[qb][kb][g] = w[g] | nomask;
+                    }
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             gen_dma(t + 1);                          // past-the-end tiles are out of range: zeros
@@ -401,7 +410,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                         if (VEC) {
                             const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
                             const float v = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), binv, -lse2[qb]);
-                            sacc[qb][r] = ((mraw[qb][kb][r >> 2] >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
+                            if (VMASK) sacc[qb][r] = ((mraw[qb][kb][r >> 2] >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
+                            else if (KP) sacc[qb][r] = (((uint32_t)(kp_bits >> (32 * kb + 16 * hi)) >> r) & 1u) ? v : -INFINITY;   // key-permuted rows: register r = key 16*hi + r
+                            else sacc[qb][r] = v;
                         } else if (KP) {   // bit (r&3) + 8(r>>2) + 4hi of this 32-key block
                             const uint32_t w = (uint32_t)(kp_bits >> (32 * kb)) >> (4 * hi);
                             sacc[qb][r] = ((w >> ((r & 3) + 8 * (r >> 2))) & 1u) ? (SEED_S ? sseed[qb][r] : 0.f) : -INFINITY;
@@ -468,7 +479,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                         for (int e = 0; e < 8; ++e) x[e] = sacc[qb][8 * t2 + e];
                         dsf[qb][kb][t2] = E::cvt8(x);
                         // gradient of the additive bias = dS (only the mask / bias instantiations carry this code)
-                        if ((MODE == MODE_GENERAL || MODE == MODE_GENERAL_SLOW) && bp.dbias != nullptr && row < p.Sq) {
+                        if ((VEC || MODE == MODE_GENERAL_SLOW) && bp.dbias != nullptr && row < p.Sq) {
                             char* drow = bp.dbias + (b * bp.dbs[0] + h * bp.dbs[1] + (int64_t)row * bp.dbs[2]) * 2;
                             uint16_t hv[8];
                             __builtin_memcpy(hv, &dsf[qb][kb][t2], 16);
@@ -575,7 +586,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
 
     int bh, kblk;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
-    const bool causal = (MODE == MODE_CAUSAL) || ((MODE == MODE_GENERAL || MODE == MODE_GENERAL_SLOW || MODE == MODE_KEYPAD) && p.causal);
+    const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
     const int b = bh / p.H, h = bh % p.H;
     const int kw0 = kblk * BN + wave * (KB * 32);  // first key of this wave
     const int coff = p.Sk - p.Sq;
@@ -691,7 +702,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     // rows or keys past the end read back as "hidden") and every wave fetches its 32 columns with the same transposed
     // read that feeds the MFMAs (ds_read_b64_tr_b16: 4 consecutive rows of one key column = accumulator registers 4g..4g+3).
     // The tile initialises the S accumulator (S' = add*log2e/c + q.k), so the element pass is the plain one.
-    constexpr bool VEC = MODE == MODE_GENERAL;
+    constexpr bool VEC = mode_is_vector(MODE);      // MODE_GENERAL, MODE_BIAS_KEYPAD (the additive tile is the bias alone; the mask is a per-lane flag)
+    constexpr bool VMASK = mode_has_vmask(MODE);
     constexpr int BN_ = 4 * KB * 32;
     constexpr int ADDB = QT * BN_ * 2;              // bytes of one additive tile = BN_/128 swizzled [64][128] images
     constexpr int ACH = (QT * BN_ / 8) / 256;       // 8-key chunks per thread
@@ -702,14 +714,14 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     const int arow0 = tid / (BN_ / 8), akc = tid % (BN_ / 8);
     u32x4 stA[ACH];
     u32x2 stM[ACH];
-    const uint32_t nomask = (VEC && p.mask == nullptr) ? 0x01010101u : 0u;
+    const uint32_t nomask = (!VMASK || p.mask == nullptr) ? 0x01010101u : 0u;
     const float binv = VEC ? kLog2e : 0.f;   // K is pre-scaled: S' = add*log2e - LSE*log2e + q.k'
     const uint32_t ninf16 = std::is_same<Tag, bf16_tag>::value ? 0xFF80u : 0xFC00u;   // -inf in the 16-bit type
     if (VEC) {
         const char* bb = p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
-        const char* mb = p.mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
+        const char* mb = (VMASK && p.mask) ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
         brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bb), 0, p.bias ? p.bias_bytes : 0u, 0x00020000);
-        mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mb), 0, p.mask ? p.mask_bytes : 0u, 0x00020000);
+        mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mb), 0, (VMASK && p.mask) ? p.mask_bytes : 0u, 0x00020000);
         abvo0 = (unsigned)((arow0 * p.bs[2] + akc * 8) * 2);
         amvo0 = (unsigned)(arow0 * p.ms[2] + akc * 8);
     }
@@ -718,7 +730,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             stA[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, abvo0, ((row0 + i * RSTEP) * (int)p.bs[2] + kcol0) * 2, 0);
-            stM[i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, amvo0, (row0 + i * RSTEP) * (int)p.ms[2] + kcol0, 0);
+            if (VMASK) stM[i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, amvo0, (row0 + i * RSTEP) * (int)p.ms[2] + kcol0, 0);
+            else stM[i] = u32x2{0u, 0u};
         }
     };
     auto add_lstore = [&](int buf) {
@@ -757,7 +770,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             }
         }
 
-    constexpr bool KPD = MODE == MODE_KEYPAD;
+    constexpr bool KPD = mode_has_keypad(MODE);
     bool kp_keep[KB];
     bool kp_none = false;
     if (KPD) {
@@ -823,7 +836,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 f32x16 sacc[KB], pacc[KB];
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
-                    if (VEC) {
+                    if (VEC && KPD && !kp_keep[kb]) {   // bias + key padding: a lane's key is hidden for every row
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[kb][r] = -INFINITY;
+                    } else if (VEC) {
                         const int cb = wave * KB + kb;   // this wave's 32-key column block inside the additive tile
 #pragma unroll
                         for (int t2 = 0; t2 < 2; ++t2) {

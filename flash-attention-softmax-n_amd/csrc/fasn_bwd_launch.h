@@ -21,7 +21,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     }
     {   // dQ
         constexpr int BM = 4 * QB * 32;
-        constexpr int smem = 4 * KT * D * 2 + (MODE == MODE_GENERAL ? 4 * QB * 6144 : 0);   // + per-wave bias / mask images
+        constexpr int smem = 4 * KT * D * 2 + (mode_is_vector(MODE) ? 4 * QB * 6144 : 0);   // + per-wave bias / mask images
         p.nblk = (p.f.Sq + BM - 1) / BM;
         constexpr auto kern = &fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q, DROP>;
         ensure_smem<kern>(smem);
@@ -29,7 +29,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     }
     {   // dK, dV
         constexpr int BN = 4 * KB * 32;
-        constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (MODE == MODE_GENERAL ? 2 * QT * BN * 2 : 0);
+        constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (mode_is_vector(MODE) ? 2 * QT * BN * 2 : 0);
         p.nblk = (p.f.Sk + BN - 1) / BN;
         constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP>;
         ensure_smem<kern>(smem);
@@ -41,6 +41,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
 template <typename Tag, int D, int QB, int KB, int OCC_Q, int OCC_K>
 int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
     if (p.f.drop_thr) {   // dropout: separate instantiations (the keep-bit hash costs registers the p = 0 kernels keep)
+        if (mode == MODE_BIAS_KEYPAD) mode = p.f.keypad_fallback;   // (no dropout instantiation of its own: the dense-mask general mode)
         switch (mode) {
             case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K, 1>(p, s);
             case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K, 1>(p, s);
@@ -54,6 +55,7 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
         case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K>(p, s);
         case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_KEYPAD, OCC_Q, OCC_K>(p, s);   // key-padding mask: plain kernels + visibility bits
         case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1>(p, s);
+        case MODE_BIAS_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1)>(p, s);   // vector bias + visibility bits
         default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1)>(p, s);   // vector path (bias and/or mask)
     }
 }

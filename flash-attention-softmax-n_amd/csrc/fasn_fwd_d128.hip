@@ -17,6 +17,7 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);
         case MODE_GENERAL_B: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);   // the bias-only instantiation spills (37 VGPRs) at D = 128
         case MODE_GENERAL_M: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_M, 2, 8, 2, 2>(p, s);
+        case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 128, 1, MODE_BIAS_KEYPAD, 2, 8, 2, 2>(p, s);
         default: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_SLOW, 1>(p, s);
     }
 }

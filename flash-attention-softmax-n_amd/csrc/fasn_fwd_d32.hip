@@ -7,6 +7,7 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, 1, 4, 0, 2>(p, s);
         case MODE_GENERAL_B: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_B, 1, 4, 0, 2>(p, s);
         case MODE_GENERAL_M: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_M, 1, 4, 0, 2>(p, s);
+        case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 32, 2, MODE_BIAS_KEYPAD, 1, 4, 0, 2>(p, s);
         default: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_SLOW, 1>(p, s);
     }
 }

@@ -36,7 +36,13 @@ namespace fasn {
 // The vector kernels are specialised at compile time on which operands exist (MODE_GENERAL_B / _M / _BM), so that every
 // load in the tile loop is unconditional and hipcc can emit counted s_waitcnt vmcnt(N) instead of draining the queue.
 enum { MODE_PLAIN = 0, MODE_CAUSAL = 1, MODE_GENERAL = 2 /* = bias + mask */, MODE_GENERAL_SLOW = 3, MODE_GENERAL_B = 4, MODE_GENERAL_M = 5,
-       MODE_KEYPAD = 6 /* boolean mask that depends on (batch, head, key) only - key padding - and no bias */ };
+       MODE_KEYPAD = 6 /* boolean mask that depends on (batch, head, key) only - key padding - and no bias */,
+       MODE_BIAS_KEYPAD = 7 /* vector bias + key-padding mask (e.g. ALiBi on a padded batch): the bias through the vector path, the mask
+                               as the per-tile visibility word of MODE_KEYPAD - no mask image, no per-element byte test, padded tiles skipped */ };
+constexpr bool mode_has_vbias(int M) { return M == MODE_GENERAL || M == MODE_GENERAL_B || M == MODE_BIAS_KEYPAD; }
+constexpr bool mode_has_vmask(int M) { return M == MODE_GENERAL || M == MODE_GENERAL_M; }
+constexpr bool mode_is_vector(int M) { return mode_has_vbias(M) || mode_has_vmask(M); }
+constexpr bool mode_has_keypad(int M) { return M == MODE_KEYPAD || M == MODE_BIAS_KEYPAD; }
 
 struct FwdParams {
     const char* q;
@@ -93,7 +99,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     constexpr bool PSUM = SEED >= 2 && !DROP;   // fast-path row sums from the packed weights
-    constexpr bool UNR3 = RING == 2 && (D <= 64 || (FASN_UNR3_D128 && NW == 8 && MODE != MODE_GENERAL && MODE != MODE_GENERAL_B && MODE != MODE_GENERAL_M));  // direct-to-LDS loop unrolled by its three buffers
+    constexpr bool UNR3 = RING == 2 && (D <= 64 || (FASN_UNR3_D128 && NW == 8 && !mode_is_vector(MODE)));  // direct-to-LDS loop unrolled by its three buffers
     constexpr bool UNR2 = RING == 0 && ABL == 0 && FASN_FWD_UNR2;   // single-set staging: loop unrolled by its two LDS buffers
     constexpr int NT = NW * 64;
     constexpr int BM = NW * QB * 32;
@@ -117,16 +123,16 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int hi = lane >> 5;
 
     int bh, qi, split = 0;
-    constexpr bool VEC = MODE == MODE_GENERAL || MODE == MODE_GENERAL_B || MODE == MODE_GENERAL_M;
+    constexpr bool VEC = mode_is_vector(MODE);
     constexpr bool SLOW = MODE == MODE_GENERAL_SLOW;
     constexpr bool GEN = VEC || SLOW;
-    constexpr bool VBIAS = MODE == MODE_GENERAL || MODE == MODE_GENERAL_B;   // vector bias present (compile time)
-    constexpr bool VMASK = MODE == MODE_GENERAL || MODE == MODE_GENERAL_M;   // vector mask present (compile time)
+    constexpr bool VBIAS = mode_has_vbias(MODE);   // vector bias present (compile time)
+    constexpr bool VMASK = mode_has_vmask(MODE);   // vector mask present (compile time)
     constexpr bool KPERM = VEC;
     // MODE_KEYPAD: the mask is one byte per key for the whole (b,h): each lane fetches the byte of key k0 + lane one tile ahead,
     // a ballot turns the 64 bytes into a wave-uniform bit word; tiles with all keys visible run as plain tiles, tiles with none
     // are skipped, only the boundary tiles start their hidden scores at -inf. Key-padded batches cost what unpadded ones do.
-    constexpr bool KP = MODE == MODE_KEYPAD;
+    constexpr bool KP = mode_has_keypad(MODE);
     if (SPLIT) {
         int blk;
         block_to_work(blockIdx.x, p.B * p.H, p.nqblk * p.nsplit, bh, blk);
@@ -390,9 +396,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         else if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
 
         uint64_t kp_bits = ~0ull;
-        if (KP) {   // this tile's visibility word; the next tile's bytes go in flight (older than the K/V prefetch in the vmcnt queue)
+        if (KP) {   // this tile's visibility word; the next tile's bytes go in flight (older than the K/V prefetch in the vmcnt queue;
+                    // vector modes: requested after the image wait below, so the counted vmcnt there sees the same queue as without it)
             kp_bits = __ballot(kp_next != 0);
-            kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
+            if (!VEC) kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
         }
         // wave-uniform tile classification
         bool skip = false;       // no visible element for this wave
@@ -434,6 +441,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     }
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before the next one is requested
+            if (KP) kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
             gen_dma(t + 1);                                        // past-the-end tiles are out of range: zeros
             if (RING == 2) stage_direct(t + 2, buf2);
             else stage_load(t + 1 + RING, LSET);
@@ -462,6 +470,16 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             if (VMASK) v = (((mraw[qb][kb][r >> 2] | nomask) >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
                             sacc[qb][kb][r] = v;
                         }
+                }
+                if (KP && kp_bits != ~0ull) {   // boundary tile of the key-padding mask (wave-uniform): hidden keys start at -inf
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const uint32_t w = (uint32_t)(kp_bits >> (32 * kb)) >> (16 * hi);   // key-permuted rows: register r = key 16*hi + r
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb) sacc[qb][kb][r] = ((w >> r) & 1u) ? sacc[qb][kb][r] : -INFINITY;
+                    }
                 }
             } else if (KP && kp_bits != ~0ull) {   // boundary tile of a key-padding mask: hidden keys start at -inf
 #pragma unroll

@@ -28,7 +28,8 @@ int launch_splitk_mode(const FwdParams& p, int mode, hipStream_t s) {
         case MODE_GENERAL:
         case MODE_GENERAL_B:
         case MODE_GENERAL_M:
-        case MODE_KEYPAD: return launch_splitk_one<Tag, D, MODE_GENERAL>(p, s);   // (the plan requires the vector-mask alignment)
+        case MODE_KEYPAD:
+        case MODE_BIAS_KEYPAD: return launch_splitk_one<Tag, D, MODE_GENERAL>(p, s);   // (the plan requires the vector-mask alignment)
         default: return -7;
     }
 }

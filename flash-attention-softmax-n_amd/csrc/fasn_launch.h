@@ -42,7 +42,7 @@ inline void ensure_smem(int smem) {
 }
 inline int launch_rc() { return hipGetLastError() == hipSuccess ? 0 : -6; }
 
-constexpr bool mode_is_vec(int MODE) { return MODE == MODE_GENERAL || MODE == MODE_GENERAL_B || MODE == MODE_GENERAL_M; }
+constexpr bool mode_is_vec(int MODE) { return mode_is_vector(MODE); }
 constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB) {
     return (RING == 2 ? 6 : 4) * KT * D * 2 + (mode_is_vec(MODE) ? NW * QB * 6144 : 0);   // K/V buffers + per-wave bias / mask images
 }
@@ -72,6 +72,7 @@ int launch_fwd_cfg(const FwdParams& p, int mode, hipStream_t s) {
 // Seeded S accumulators; the row sums stay fp32 (taken before the drop).
 template <typename Tag, int D, int QB, int OCC>
 int launch_fwd_drop(const FwdParams& p, int mode, hipStream_t s) {
+    if (mode == MODE_BIAS_KEYPAD) mode = p.keypad_fallback;   // no dropout instantiation of its own: the dense-mask general mode
     if (mode == MODE_PLAIN) return launch_fwd_one<Tag, D, QB, MODE_PLAIN, OCC, 4, 0, 1, 1>(p, s);
     if (mode == MODE_CAUSAL) return launch_fwd_one<Tag, D, QB, MODE_CAUSAL, OCC, 4, 0, 1, 1>(p, s);
     if (mode == MODE_KEYPAD) return launch_fwd_one<Tag, D, QB, MODE_KEYPAD, OCC, 4, 0, 1, 1>(p, s);

@@ -36,7 +36,7 @@ def _check(got, want, dtype, what):
 
 def _oracle_fwd_bwd(q, k, v, do, **kw):
     qc, kc, vc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v))
-    kw = {a: (b.detach().cpu() if torch.is_tensor(b) else b) for a, b in kw.items()}
+    kw = {a: ((b.detach().cpu() if b.is_cuda else b) if torch.is_tensor(b) else b) for a, b in kw.items()}
     o = ref_attention_n(qc, kc, vc, **kw)
     o.backward(do.detach().cpu().float())
     return o, qc.grad, kc.grad, vc.grad
@@ -772,20 +772,25 @@ def test_attn_bias_gradient(pkg, dev, D, kind, dtype):
             _check(got, want, dtype, f"{kind}/{nm}")
 
 
-# ---------------------------------------------------------------- key-padding masks (MODE_KEYPAD)
+# ---------------------------------------------------------------- key-padding masks (MODE_KEYPAD, MODE_BIAS_KEYPAD)
 @pytest.mark.parametrize("D", [32, 64, 128])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("pattern", ["tail", "random", "blocks", "none_visible_in_one_batch"])
 @pytest.mark.parametrize("n", [1.0, 0.0])
-def test_key_masks_with_row_stride_zero(pkg, dev, n, pattern, causal, D):
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_key_masks_with_row_stride_zero(pkg, dev, with_bias, n, pattern, causal, D):
     """boolean masks that depend on (batch, head, key) only take the per-tile visibility-word path: hidden keys anywhere in the
     sequence, whole hidden tiles (skipped), a batch element with no visible key at all, per-head masks, odd key counts.
     n = 0: no sink column, so a row has no finite max until its first visible key (left padding: the first tiles are hidden) and
-    the seeded kernels must stay on the exact path until then"""
+    the seeded kernels must stay on the exact path until then.
+    with_bias: the same masks next to an additive [H,L,S] bias that requires grad (MODE_BIAS_KEYPAD: ALiBi-style bias on a padded
+    batch - the bias goes through the vector path, the mask stays a visibility word); dbias is checked too."""
     if n == 0.0 and pattern == "none_visible_in_one_batch":
         pytest.skip("softmax_0 over an empty key set is 0/0 in the oracle")
     dtype = torch.bfloat16
     B, H, L, S = 3, 2, 200, 331
+    if with_bias:
+        S = 336   # bias rows 16-byte aligned: the vector path (an unaligned bias takes the element-load kernels, covered elsewhere)
     q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
     do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
     gen = torch.Generator().manual_seed(21)
@@ -802,11 +807,18 @@ def test_key_masks_with_row_stride_zero(pkg, dev, n, pattern, causal, D):
         mask = torch.ones(B, 1, 1, S, dtype=torch.bool)
         mask[1] = False
     mask = mask.to(dev)
-    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, attn_mask=mask, is_causal=causal)
+    bias = bc = None
+    if with_bias:
+        bias = (1.5 * torch.randn(H, L, S, generator=gen)).to(dtype).to(dev).requires_grad_()
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, attn_mask=mask, attn_bias=bias, is_causal=causal)
     out.backward(do)
-    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=n, attn_mask=mask, is_causal=causal)
+    if with_bias:
+        bc = bias.detach().cpu().float().requires_grad_()
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=n, attn_mask=mask, is_causal=causal, attn_bias=bc)
     for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
         _check(got, want, dtype, f"{pattern}/{nm}")
+    if with_bias:
+        _check(bias.grad, bc.grad, dtype, f"{pattern}/dbias")
     if pattern == "none_visible_in_one_batch":
         assert (out[1] == 0).all() and (k.grad[1] == 0).all() and (v.grad[1] == 0).all()
 
