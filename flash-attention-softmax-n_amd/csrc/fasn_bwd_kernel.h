@@ -836,10 +836,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 f32x16 sacc[KB], pacc[KB];
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
-                    if (VEC && KPD && !kp_keep[kb]) {   // bias + key padding: a lane's key is hidden for every row
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sacc[kb][r] = -INFINITY;
-                    } else if (VEC) {
+                    if (VEC) {   // (all lanes take part in the transposed read; a lane whose key is padded overrides its values below)
                         const int cb = wave * KB + kb;   // this wave's 32-key column block inside the additive tile
 #pragma unroll
                         for (int t2 = 0; t2 < 2; ++t2) {
@@ -848,6 +845,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                             __builtin_memcpy(ab, &av, 16);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) sacc[kb][8 * t2 + e] = __builtin_fmaf(E::to_f32(ab[e]), binv, lr[8 * t2 + e]);
+                        }
+                        if (KPD) {   // bias + key padding: a lane's key is hidden for every row
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sacc[kb][r] = kp_keep[kb] ? sacc[kb][r] : -INFINITY;
                         }
                     } else if (KPD && !kp_keep[kb]) {   // key-padding: a lane's key is hidden for every row
 #pragma unroll
