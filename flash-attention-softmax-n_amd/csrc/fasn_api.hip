@@ -9,6 +9,9 @@
 using namespace fasn;
 
 namespace fasn {
+#ifdef FASN_DEV_VARIANTS
+int g_bwd_variant = 0;
+#endif
 int launch_fwd_f32(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_f32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 }  // namespace fasn
@@ -244,6 +247,8 @@ int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_byt
 }
 
 #ifdef FASN_DEV_VARIANTS
+// developer library only (tools/libfasn_dev.so): backward A/B switch (see fasn_bwd_launch.h)
+void fasn_dev_set_bwd_variant(int v) { fasn::g_bwd_variant = v; }
 // developer library only (tools/libfasn_dev.so): forward with an explicit tuning variant, used by tools/fasn_harness
 int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant) {
     FwdParams p;

@@ -1,0 +1,417 @@
+// fasn_bwd_dkdv_ws.h — dK / dV with the four GEMMs of a score block split over TWO cooperating waves of one SIMD.
+//
+// The one-wave kernel (fasn_bwd_dkdv_kernel) keeps dK and dV accumulators, the K and V fragments and both score-shaped
+// accumulators in one wave: 376 registers at D = 128, so one wave per SIMD, whose LDS latency, accumulator <-> AGPR copies and
+// element pass all sit in series with its MFMAs (31 % of the MFMA peak). Here a workgroup has 8 waves for 128 keys; the waves
+// w and w + 4 share a SIMD and the same 32 keys and divide the work of a [32 rows x 32 keys] block by GEMM, not by data:
+//
+//   wave A (w < 4):  S = Q K'^T (seeded with -LSE)  ->  P = exp2(S)  ->  P (16 bit) to LDS  ->  dV^T += dO^T P
+//   wave B (w >= 4): dP' = dO V^T (seeded with -delta), reads P from LDS  ->  dS = P o dP'   ->  dK^T += Q^T dS
+//
+// Each wave holds ONE output accumulator and ONE operand fragment set (about 180-200 registers: two waves per SIMD, no AGPR
+// traffic), each issues 16 of the block's 32 MFMAs, and the only exchange is A's packed P (2 KiB per block, lane to same
+// lane: both waves hold [row][key] tiles in the same accumulator layout). B runs ONE q-tile behind A, so the P of tile t is
+// published by the barrier that ends A's iteration t anyway: one barrier per q-tile, no extra synchronisation. Q / dO tiles
+// live in three LDS buffers (tile t for A, t-1 for B, t+1 in flight), P in two.
+// Mask / bias work exists in wave A only (B just receives zeros for hidden scores). The additive bias of a block ([32 rows] x
+// the wave's [32 keys], 2 KiB) goes HBM -> LDS by `buffer_load_dword ... lds` into a WAVE-PRIVATE ring of three slots, three
+// blocks (one and a half q-tiles) ahead: private, so no barrier is involved - the wave re-requests a slot right after reading
+// it - and no register is written asynchronously (the waits are hand-counted vmcnt next to the Q / dO requests). A lane owns a
+// key column, so it reads its 16 rows of a block with 16 two-byte LDS reads. A key-padding mask is one flag per lane.
+// Dense boolean masks (MODE_GENERAL) stay on the one-wave kernel.
+#pragma once
+#include "fasn_bwd_kernel.h"
+
+namespace fasn {
+
+#ifndef FASN_WS_ATTR
+#define FASN_WS_ATTR
+#endif
+template <typename Tag, int D, int MODE>
+__global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(const BwdParams bp) {
+    using E = ET<Tag>;
+    using vec8 = typename E::vec8;
+    const FwdParams& p = bp.f;
+    constexpr int BN = 128;               // keys per workgroup: 4 key blocks x (A wave + B wave)
+    constexpr int TILEB = QT * D * 2;
+    constexpr int KS = D / 16;
+    constexpr int DB = D / 32;
+    constexpr int CPR = D / 8;
+    constexpr int NLD = (QT * CPR) / 512;  // 16-byte chunks per thread per tile
+    static_assert(NLD >= 1, "tile too small for 512 threads");
+    constexpr int PBUF = 4 * 2 * 2048;     // one P buffer: [4 key blocks][2 row blocks][2 KiB]
+    constexpr bool VBIAS = mode_has_vbias(MODE);
+    constexpr bool KPD = mode_has_keypad(MODE);
+    static_assert(MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE), "element-load and dense-mask modes stay on the one-wave kernel");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsQ = smem;                    // [3][TILEB]
+    char* const ldsDO = smem + 3 * TILEB;       // [3][TILEB]
+    char* const ldsP = smem + 6 * TILEB;        // [2][PBUF]
+    float* const ldsLse = reinterpret_cast<float*>(smem + 6 * TILEB + 2 * PBUF);   // [3][QT]  -lse*log2e
+    float* const ldsDlt = ldsLse + 3 * QT;                                          // [3][QT]  -delta
+    char* const ldsBias = reinterpret_cast<char*>(ldsDlt + 3 * QT);                 // [4 A waves][3 slots][32 rows][64 B] (bias modes)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+    const int role = wave >> 2;    // 0 = A (S, P, dV), 1 = B (dP, dS, dK)
+    const int kbw = wave & 3;      // key block of this wave inside the workgroup's 128 keys
+
+    int bh, kblk;
+    if (VBIAS && p.batch_inner && (p.H & 7) == 0) {
+        // per XCD: (head, key block, batch) with the batch fastest: the B workgroups that read the same bias columns run together
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int bb = j % p.B, rest = j / p.B;
+        kblk = rest % bp.nblk;
+        bh = bb * p.H + (rest / bp.nblk) * 8 + xcd;
+    } else {
+        block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
+    }
+    const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
+    const int b = bh / p.H, h = bh % p.H;
+    const int kw0 = kblk * BN + kbw * 32;   // first key of this wave
+    const int key = kw0 + l31;
+    const int coff = p.Sk - p.Sq;
+
+    const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
+    const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2;
+    const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2;
+    const float* lsebase = p.lse + (int64_t)bh * p.Sq;
+    const float* dltbase = bp.delta + (int64_t)bh * p.Sq;
+
+    const int ntq = (p.Sq + QT - 1) / QT;
+    int tq0 = 0;
+    if (causal) {
+        const int first_row = kblk * BN - coff;
+        tq0 = first_row <= 0 ? 0 : first_row / QT;
+    }
+
+    // this wave's operand fragment: K (pre-scaled by c = scale*log2e) for A, V for B  (B operand: col = key, k = 8 features)
+    vec8 opf[KS];
+    {
+        const bool ok = key < p.Sk;
+        const char* rp = (role == 0 ? kbase + (int64_t)key * p.ks[2] * 2 : vbase + (int64_t)key * p.vs[2] * 2) + hi * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 a = {0u, 0u, 0u, 0u};
+            if (ok) a = gload16(rp + s * 32);
+            __builtin_memcpy(&opf[s], &a, 16);
+        }
+    }
+    f32x16 acc[DB];   // dV^T (A) or dK^T (B): [feature][key]
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+    // ---- Q / dO tiles straight to LDS: thread `tid` owns slots tid + 512*i of a tile image
+    unsigned voffQ[NLD], voffD[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int ci = tid + i * 512;
+        const int row = ci / CPR, ch = (ci % CPR) ^ swz_f<D>(row);
+        voffQ[i] = (unsigned)(row * (int)p.qs[2] * 2 + ch * 16);
+        voffD[i] = (unsigned)(row * (int)bp.dos[2] * 2 + ch * 16);
+    }
+    const u32x4 qrw = make_rsrc_words(qbase, bp.qbytes), drw = make_rsrc_words(dobase, bp.dobytes);
+    const uint32_t ldsQ_w = lds_addr(ldsQ) + wave * 1024, ldsDO_w = lds_addr(ldsDO) + wave * 1024;
+    auto tile_dma = [&](int tq, int buf) {
+        const int sq = tq * QT * (int)p.qs[2] * 2, sd = tq * QT * (int)bp.dos[2] * 2;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            lds_dma16(qrw, __builtin_amdgcn_readfirstlane(ldsQ_w + buf * TILEB + i * 8192), voffQ[i], sq);
+            lds_dma16(drw, __builtin_amdgcn_readfirstlane(ldsDO_w + buf * TILEB + i * 8192), voffD[i], sd);
+        }
+    };
+    // per-row statistics of a tile, NEGATED (they are the start values of the S / dP accumulators); rows past Sq: lse = +inf.
+    // Loaded by wave 4 (a B wave): its only other vector-memory requests are the Q / dO pieces it drains at the end of every
+    // iteration anyway, so the compiler's own wait for these two loads costs nothing (in an A wave it would also drain the
+    // bias requests that are meant to stay in flight).
+    float stL = 0.f, stX = 0.f;
+    const int stid = tid - 256;
+    auto stats_gload = [&](int row0) {
+        if (stid >= 0 && stid < QT) {
+            const int gr = row0 + stid;
+            float l = INFINITY, x = 0.f;
+            if (gr < p.Sq) {
+                l = lsebase[gr];
+                x = dltbase[gr];
+            }
+            stL = (l == -INFINITY || l == INFINITY) ? -INFINITY : -l * kLog2e;   // a row without weights: every P = exp2(-inf) = 0
+            stX = -x;
+        }
+    };
+    auto stats_lstore = [&](int buf) {
+        if (stid >= 0 && stid < QT) {
+            ldsLse[buf * QT + stid] = stL;
+            ldsDlt[buf * QT + stid] = stX;
+        }
+    };
+
+    // key padding: one flag per lane for the whole kernel
+    bool kp_keep = true, kp_none = false;
+    if (KPD) {
+        kp_keep = key < p.Sk && (p.mask == nullptr || p.mask[b * p.ms[0] + h * p.ms[1] + key] != 0);   // (no mask: a bias-only call)
+        kp_none = !__any(kp_keep);
+    }
+    // additive bias (wave A): block bq = 2*(tile - tq0) + row block lives in slot bq % 3 of the wave's ring as [32 rows][64 B]
+    // (32 keys, row-major). One request = 8 x `buffer_load_dword ... lds` (4 rows x 16 dwords each); rows / keys past the end
+    // read 0 (range check), so requests past the last block are simply issued like the others and the counts stay uniform.
+    u32x4 brw = {0u, 0u, 0u, 0u};
+    unsigned bvo = 0;
+    if (VBIAS) {
+        brw = make_rsrc_words(p.bias + (b * p.bs[0] + h * p.bs[1]) * 2, p.bias_bytes);
+        bvo = (unsigned)(((lane >> 4) * (int)p.bs[2] + kw0 + 2 * (lane & 15)) * 2);
+    }
+    const uint32_t ring_a = lds_addr(ldsBias) + kbw * (3 * 2048);
+    auto bias_request = [&](int row0, int slot) {   // 8 vector-memory requests
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            lds_dma4(brw, __builtin_amdgcn_readfirstlane(ring_a + slot * 2048 + i * 256), bvo, (row0 + 4 * i) * (int)p.bs[2] * 2);
+    };
+    const char* const ring_rd = ldsBias + kbw * (3 * 2048) + (4 * hi) * 64 + l31 * 2;   // this lane's key, rows 4hi + ...
+    using Set0 = std::integral_constant<int, 0>;
+
+    if (tq0 < ntq) {
+        tile_dma(tq0, 0);
+        stats_gload(tq0 * QT);
+        stats_lstore(0);
+        if (VBIAS && role == 0) {
+            bias_request(tq0 * QT, 0);
+            bias_request(tq0 * QT + 32, 1);
+            bias_request(tq0 * QT + 64, 2);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) retire_loads(opf[s]);
+    if (role == 0) {   // K' = K * scale*log2e, rounded to the operand type (like the pre-scaled q of core/flash_attn.py:81-83)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint16_t hk[8];
+            __builtin_memcpy(hk, &opf[s], 16);
+            f32x8 f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hk[e]) * p.c;
+            opf[s] = E::cvt8(f);
+        }
+    }
+
+    // wave-uniform classification of (q tile tq) x (this wave's 32 keys): identical for the A and the B wave of a key block
+    auto classify = [&](int tq, bool& skip, bool& need_mask) {
+        const int r0 = tq * QT;
+        skip = kw0 >= p.Sk;
+        need_mask = false;
+        if (causal) {
+            skip = skip || (r0 + QT - 1 + coff) < kw0;              // even the last row sees none of my keys
+            need_mask = (r0 + coff) < (kw0 + 31);                   // the first row does not see all my keys
+        }
+        if (r0 + QT > p.Sq || kw0 + 32 > p.Sk) need_mask = true;
+        if (KPD && kp_none) skip = true;                            // none of this wave's keys is visible to anybody
+    };
+    // P exchange slot of (P buffer, key block, row block): 2 KiB = lane * 16 bytes, twice
+    auto pslot = [&](int pb, int qb) { return ldsP + pb * PBUF + (kbw * 2 + qb) * 2048 + lane * 16; };
+
+    // ---- wave A: one q tile (it also requests the next tile: between its bias waits, so that their counts are exact)
+    auto tile_a = [&](const int tq, auto BUF_, auto BN_, const int pb) {
+        constexpr int buf = decltype(BUF_)::value;
+        const int r0 = tq * QT;
+        const char* tQ = ldsQ + buf * TILEB;
+        const char* tD = ldsDO + buf * TILEB;
+        const float* tL = ldsLse + buf * QT;
+        const bool more = tq + 1 < ntq;
+        bool skip, need_mask;
+        classify(tq, skip, need_mask);
+        // start value of the S accumulator: -lse*log2e of the register's row (+ bias*log2e; -inf where the lane's key is padded)
+        auto start = [&](int qb, int slot, f32x16& sacc) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = *LDS_PTR(const f32x4, tL + qb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    float v = a[e];
+                    if (VBIAS) v = __builtin_fmaf(E::to_f32(*LDS_PTR(const uint16_t, ring_rd + slot * 2048 + ((r & 3) + 8 * (r >> 2)) * 64)), kLog2e, v);
+                    if (KPD) v = kp_keep ? v : -INFINITY;
+                    sacc[r] = v;
+                }
+            }
+        };
+        auto block = [&](int qb, f32x16& sacc) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const vec8 qa = lds_read_rowfrag<E, D>(tQ, qb * 32 + l31, s, hi);
+                sacc = E::mfma(qa, opf[s], sacc);
+            }
+            vec8 pfr[2];
+            auto elems = [&](auto MASKED) {
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    f32x8 x;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = 8 * t2 + e;
+                        float pv = fast_exp2(sacc[r]);
+                        if (decltype(MASKED)::value) {
+                            const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const bool show = (key < p.Sk) && (row < p.Sq) && (!causal || key <= row + coff);
+                            pv = show ? pv : 0.f;
+                        }
+                        x[e] = pv;
+                    }
+                    pfr[t2] = E::cvt8(x);
+                }
+            };
+            if (need_mask) elems(std::true_type{});
+            else elems(std::false_type{});
+            {   // publish P (16 bit) for the partner wave: lane to same lane, 2 x 16 bytes
+                char* ps = pslot(pb, qb);
+                u32x4 w0, w1;
+                __builtin_memcpy(&w0, &pfr[0], 16);
+                __builtin_memcpy(&w1, &pfr[1], 16);
+                *LDS_PTR(u32x4, ps) = w0;
+                *LDS_PTR(u32x4, ps + 1024) = w1;
+            }
+            // dV^T[d][key] += dO^T[d][q] P[q][key]
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const vec8 dot = lds_read_trfrag<E, D>(tD, qb * 32 + 16 * t2, d, lane);
+                    acc[d] = E::mfma(dot, pfr[t2], acc[d]);
+                }
+        };
+        f32x16 sacc;
+        // Request order of this wave per tile: [bias block bq+3 (8)] [next Q / dO tile (2*NLD)] ... [bias block bq+4 (8)]; the wait
+        // that ends an iteration leaves only the last 8 in flight, so both blocks read here landed at least one barrier ago and
+        // the counted waits below are no-ops that pin the order. A slot is re-requested right after its reads were issued (the
+        // data of a request arrives hundreds of cycles after the reads have left the LDS queue).
+        constexpr int slot0 = (2 * buf) % 3, slot1 = (2 * buf + 1) % 3;   // buf = (tq - tq0) % 3
+        if (VBIAS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 + 2 * NLD) : "memory");
+        start(0, slot0, sacc);
+        if (VBIAS) bias_request(r0 + QT + 32, slot0);   // block bq + 3 = second block of the next tile (the reads above were issued first)
+        if (more) tile_dma(tq + 1, decltype(BN_)::value);
+        if (!skip) block(0, sacc);
+        if (VBIAS) {
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 + 2 * NLD) : "memory");   // (the tile before this one's was waited for at the barrier)
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        }
+        start(1, slot1, sacc);
+        if (VBIAS) bias_request(r0 + 2 * QT, slot1);    // block bq + 4 = first block of the tile after the next
+        if (!skip) block(1, sacc);
+    };
+
+    // ---- wave B: one q tile (the one wave A finished in the previous iteration)
+    auto tile_b = [&](const int tq, auto BUF_, const int pb) {
+        constexpr int buf = decltype(BUF_)::value;
+        const char* tQ = ldsQ + buf * TILEB;
+        const char* tD = ldsDO + buf * TILEB;
+        const float* tX = ldsDlt + buf * QT;
+        bool skip, need_mask;
+        classify(tq, skip, need_mask);
+        if (!skip) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16 pacc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 c = *LDS_PTR(const f32x4, tX + qb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pacc[4 * g + e] = c[e];
+                }
+                const char* ps = pslot(pb, qb);
+                const u32x4 w0 = *LDS_PTR(const u32x4, ps), w1 = *LDS_PTR(const u32x4, ps + 1024);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const vec8 da = lds_read_rowfrag<E, D>(tD, qb * 32 + l31, s, hi);
+                    pacc = E::mfma(da, opf[s], pacc);
+                }
+                // dS = P o (dP - delta): P arrives rounded to 16 bit (the value dV was accumulated with)
+                vec8 dsf[2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const u32x4 w = t2 == 0 ? w0 : w1;
+                    f32x8 x;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t word = w[e >> 1];
+                        const float pv = E::to_f32((uint16_t)((e & 1) ? (word >> 16) : (word & 0xffffu)));
+                        x[e] = pv * pacc[8 * t2 + e];
+                    }
+                    dsf[t2] = E::cvt8(x);
+                }
+                // dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) {
+                        const vec8 qt = lds_read_trfrag<E, D>(tQ, qb * 32 + 16 * t2, d, lane);
+                        acc[d] = E::mfma(qt, dsf[t2], acc[d]);
+                    }
+            }
+        }
+    };
+
+    // iteration t: A works on tile t, B on tile t-1, tile t+1 is in flight. Buffers relative to tq0; the loop is unrolled by the
+    // three Q / dO buffers so that their offsets are compile-time constants (they fold into the ds_read immediates). Each role
+    // runs its OWN copy of the loop (same trip count, same barriers): the loop-invariant LDS addresses of a role are then
+    // hoisted into that role's branch only, instead of both sets staying live across one shared loop.
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using B2 = std::integral_constant<int, 2>;
+    auto run = [&](auto ROLE_) {
+        constexpr int ROLE = decltype(ROLE_)::value;
+        auto body = [&](const int t, auto BA_, auto BB_, auto BN_) {
+            if (ROLE == 0) {
+                if (t < ntq) tile_a(t, BA_, BN_, (t - tq0) & 1);   // (t == ntq: nothing left to request either)
+            } else {
+                if (t + 1 < ntq) {
+                    tile_dma(t + 1, decltype(BN_)::value);
+                    stats_gload((t + 1) * QT);
+                }
+                if (t > tq0) tile_b(t - 1, BB_, (t - 1 - tq0) & 1);
+            }
+            if (ROLE == 1 && t + 1 < ntq) stats_lstore(decltype(BN_)::value);
+            // tile t+1 has landed. Wave A in the bias modes leaves its newest bias request (8 pieces, issued after the tile's) in flight
+            if (VBIAS && ROLE == 0 && t < ntq) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        for (int t = tq0; t <= ntq; t += 3) {
+            body(t, B0{}, B2{}, B1{});
+            if (t + 1 <= ntq) body(t + 1, B1{}, B0{}, B2{});
+            if (t + 2 <= ntq) body(t + 2, B2{}, B1{}, B0{});
+        }
+    };
+    if (tq0 < ntq) {
+        if (role == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue: A writes dV, B writes dK * scale
+    if (key < p.Sk) {
+        char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + h * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 2
+                             : bp.dk + (b * bp.dks[0] + h * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
+        const float sc = role == 0 ? 1.0f : bp.scale;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = acc[d][4 * g + e] * sc;
+                typename E::vec4 y = E::cvt4(x);
+                u32x2 raw;
+                __builtin_memcpy(&raw, &y, 8);
+                gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
+            }
+    }
+}
+
+
+}  // namespace fasn

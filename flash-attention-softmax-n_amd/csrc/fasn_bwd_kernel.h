@@ -328,9 +328,11 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     constexpr bool KP = mode_has_keypad(MODE);
     __amdgpu_buffer_rsrc_t kprs;
     uint32_t kp_next = 0;
+    const uint32_t kp_or = (KP && p.mask == nullptr) ? 1u : 0u;   // bias-only call through the bias + key-padding instantiation: every key visible
     if (KP) {
-        kprs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.mask + (b * p.ms[0] + h * p.ms[1])), 0, (unsigned)p.Sk, 0x00020000);
-        kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, 0, 0);
+        kprs = __builtin_amdgcn_make_buffer_rsrc(p.mask ? const_cast<uint8_t*>(p.mask + (b * p.ms[0] + h * p.ms[1])) : reinterpret_cast<uint8_t*>(const_cast<char*>(p.q)),
+                                                 0, p.mask ? (unsigned)p.Sk : 0u, 0x00020000);
+        kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, 0, 0) | kp_or;
     }
 
     // the loop is unrolled by its two LDS buffers: the buffer offset is a compile-time constant and folds into the ds_read
@@ -343,7 +345,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         uint64_t kp_bits = ~0ull;
         if (KP && !VEC) {
             kp_bits = __ballot(kp_next != 0);
-            kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
+            kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0) | kp_or;
         }
         uint32_t mraw[QB][2][4];
         u32x2 braw[QB][2][4];
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's image (and its visibility bytes) have landed
             if (KP) {   // the next tile's bytes are requested after the wait, so it does not cover their latency
                 kp_bits = __ballot(kp_next != 0);
-                kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
+                kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0) | kp_or;
             }
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fasn_bwd_kernel.h"
+#include "fasn_bwd_dkdv_ws.h"
 #include "fasn_launch.h"
 
 namespace fasn {
@@ -11,7 +12,16 @@ int launch_bwd_d32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d128(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 
-template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, int DROP = 0>
+// developer switch (FASN_DEV_VARIANTS builds only): 1 = take the one-wave dK/dV kernel where the two-wave kernel is the default
+#ifdef FASN_DEV_VARIANTS
+extern int g_bwd_variant;
+#define FASN_BWD_VARIANT g_bwd_variant
+#else
+#define FASN_BWD_VARIANT 0
+#endif
+
+// WS = 1: dK / dV by the two-wave kernel (fasn_bwd_dkdv_ws.h); not for dropout or the element-load mode
+template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, int DROP = 0, int WS = 0>
 int launch_bwd_one(BwdParams p, hipStream_t s) {
     const int nbh = p.f.B * p.f.H;
     {   // delta
@@ -27,6 +37,16 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         ensure_smem<kern>(smem);
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
     }
+    if constexpr (WS != 0 && DROP == 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
+        if (FASN_BWD_VARIANT != 1) {   // dK, dV: two cooperating waves per key block
+            constexpr int smem = 6 * QT * D * 2 + 2 * 16384 + 6 * QT * 4 + (mode_has_vbias(MODE) ? 4 * 3 * 2048 : 0);
+            p.nblk = (p.f.Sk + 127) / 128;
+            constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE>;
+            ensure_smem<kern>(smem);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+            return launch_rc();
+        }
+    }
     {   // dK, dV
         constexpr int BN = 4 * KB * 32;
         constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (mode_is_vector(MODE) ? 2 * QT * BN * 2 : 0);
@@ -38,7 +58,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     return launch_rc();
 }
 
-template <typename Tag, int D, int QB, int KB, int OCC_Q, int OCC_K>
+template <typename Tag, int D, int QB, int KB, int OCC_Q, int OCC_K, int WS = 0>
 int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
     if (p.f.drop_thr) {   // dropout: separate instantiations (the keep-bit hash costs registers the p = 0 kernels keep)
         if (mode == MODE_BIAS_KEYPAD) mode = p.f.keypad_fallback;   // (no dropout instantiation of its own: the dense-mask general mode)
@@ -51,12 +71,15 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
         }
     }
     switch (mode) {
-        case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K>(p, s);
-        case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K>(p, s);
-        case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_KEYPAD, OCC_Q, OCC_K>(p, s);   // key-padding mask: plain kernels + visibility bits
+        case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K, 0, WS>(p, s);
+        case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K, 0, WS>(p, s);
+        case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_KEYPAD, OCC_Q, OCC_K, 0, WS>(p, s);   // key-padding mask: plain kernels + visibility bits
         case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1>(p, s);
-        case MODE_BIAS_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1)>(p, s);   // vector bias + visibility bits
-        default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1)>(p, s);   // vector path (bias and/or mask)
+        case MODE_BIAS_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 0, WS>(p, s);   // vector bias + visibility bits
+        case MODE_GENERAL_B:   // bias only: with the two-wave dK/dV kernel the same instantiation without a mask (every key kept)
+            if constexpr (WS != 0) return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 0, WS>(p, s);
+            else return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1)>(p, s);
+        default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 0, WS>(p, s);   // vector path (bias and/or mask)
     }
 }
 

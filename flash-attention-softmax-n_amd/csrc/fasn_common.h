@@ -146,6 +146,12 @@ FASN_DEV void lds_dma16(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t s
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
                  : "memory", "m0");
 }
+// 4 bytes per lane into LDS (LDS byte address = lds_base + 4*lane): used as an L2 PREFETCH - the data lands in a junk area
+// nobody reads, no register is written, so the request may stay in flight as long as it likes
+FASN_DEV void lds_dma4(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory", "m0");
+}
 // raw buffer descriptor (stride 0, range-checked on `bytes`) as four SGPR words
 FASN_DEV u32x4 make_rsrc_words(const void* base, uint32_t bytes) {
     const uint64_t a = reinterpret_cast<uint64_t>(base);

@@ -16,6 +16,7 @@
 #include "fasn.h"
 
 extern "C" int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant);
+extern "C" void fasn_dev_set_bwd_variant(int v);   // 1 = one-wave dK/dV kernel where the two-wave kernel is the default
 
 #define HIP_CHECK(x)                                                                         \
     do {                                                                                     \
@@ -460,7 +461,7 @@ static int do_test(int variant, bool quick) {
 
 static int do_bench(int argc, char** argv) {
     if (argc < 9) {
-        fprintf(stderr, "bench B H Sq Sk D dtype(0=f16,1=bf16) causal [variant] [iters] [bwd] [n] [mask_kind] [bias_kind]\n");
+        fprintf(stderr, "bench B H Sq Sk D dtype(0=f16,1=bf16) causal [variant] [iters] [bwd] [n] [mask_kind] [bias_kind] [bwd_variant]\n");
         return 2;
     }
     Problem P = mk(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]), 1.f);
@@ -470,6 +471,7 @@ static int do_bench(int argc, char** argv) {
     if (argc > 12) P.n = (float)atof(argv[12]);
     if (argc > 13) P.mask_kind = atoi(argv[13]);
     if (argc > 14) P.bias_kind = atoi(argv[14]);
+    if (argc > 15) fasn_dev_set_bwd_variant(atoi(argv[15]));
     Host h;
     make_inputs(P, h, 3);
     Dev d;
