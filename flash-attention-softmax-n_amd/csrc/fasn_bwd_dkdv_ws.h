@@ -83,11 +83,19 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     const float* lsebase = p.lse + (int64_t)bh * p.Sq;
     const float* dltbase = bp.delta + (int64_t)bh * p.Sq;
 
-    const int ntq = (p.Sq + QT - 1) / QT;
+    int ntq = (p.Sq + QT - 1) / QT;
     int tq0 = 0;
     if (causal) {
         const int first_row = kblk * BN - coff;
         tq0 = first_row <= 0 ? 0 : first_row / QT;
+    }
+    // key padding: one flag per lane for the whole kernel. A workgroup none of whose 128 keys is visible (the padded tail of a
+    // batch element) has nothing to accumulate: it walks no q-tile at all and just writes its zeros.
+    bool kp_keep = true, kp_none = false;
+    if (mode_has_keypad(MODE)) {
+        kp_keep = key < p.Sk && (p.mask == nullptr || p.mask[b * p.ms[0] + h * p.ms[1] + key] != 0);   // (no mask: a bias-only call)
+        kp_none = !__any(kp_keep);
+        if (__syncthreads_or(kp_keep ? 1 : 0) == 0) ntq = tq0;
     }
 
     // this wave's operand fragment: K (pre-scaled by c = scale*log2e) for A, V for B  (B operand: col = key, k = 8 features)
@@ -152,12 +160,6 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
         }
     };
 
-    // key padding: one flag per lane for the whole kernel
-    bool kp_keep = true, kp_none = false;
-    if (KPD) {
-        kp_keep = key < p.Sk && (p.mask == nullptr || p.mask[b * p.ms[0] + h * p.ms[1] + key] != 0);   // (no mask: a bias-only call)
-        kp_none = !__any(kp_keep);
-    }
     // additive bias (wave A): block bq = 2*(tile - tq0) + row block lives in slot bq % 3 of the wave's ring as [32 rows][64 B]
     // (32 keys, row-major). One request = 8 x `buffer_load_dword ... lds` (4 rows x 16 dwords each); rows / keys past the end
     // read 0 (range check), so requests past the last block are simply issued like the others and the counts stay uniform.
@@ -242,42 +244,38 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
                 }
             }
         };
-        auto block = [&](int qb, f32x16& sacc) {
+        auto s_gemm = [&](int qb, f32x16& sacc) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const vec8 qa = lds_read_rowfrag<E, D>(tQ, qb * 32 + l31, s, hi);
                 sacc = E::mfma(qa, opf[s], sacc);
             }
-            vec8 pfr[2];
-            auto elems = [&](auto MASKED) {
+        };
+        auto soft = [&](int qb, const f32x16& sacc, vec8 (&pfr)[2], auto MASKED) {   // P = exp2(S'), packed, and published for wave B
 #pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {
-                    f32x8 x;
+            for (int t2 = 0; t2 < 2; ++t2) {
+                f32x8 x;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int r = 8 * t2 + e;
-                        float pv = fast_exp2(sacc[r]);
-                        if (decltype(MASKED)::value) {
-                            const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            const bool show = (key < p.Sk) && (row < p.Sq) && (!causal || key <= row + coff);
-                            pv = show ? pv : 0.f;
-                        }
-                        x[e] = pv;
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * t2 + e;
+                    float pv = fast_exp2(sacc[r]);
+                    if (decltype(MASKED)::value) {
+                        const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const bool show = (key < p.Sk) && (row < p.Sq) && (!causal || key <= row + coff);
+                        pv = show ? pv : 0.f;
                     }
-                    pfr[t2] = E::cvt8(x);
+                    x[e] = pv;
                 }
-            };
-            if (need_mask) elems(std::true_type{});
-            else elems(std::false_type{});
-            {   // publish P (16 bit) for the partner wave: lane to same lane, 2 x 16 bytes
-                char* ps = pslot(pb, qb);
-                u32x4 w0, w1;
-                __builtin_memcpy(&w0, &pfr[0], 16);
-                __builtin_memcpy(&w1, &pfr[1], 16);
-                *LDS_PTR(u32x4, ps) = w0;
-                *LDS_PTR(u32x4, ps + 1024) = w1;
+                pfr[t2] = E::cvt8(x);
             }
-            // dV^T[d][key] += dO^T[d][q] P[q][key]
+            char* ps = pslot(pb, qb);   // lane to same lane, 2 x 16 bytes
+            u32x4 w0, w1;
+            __builtin_memcpy(&w0, &pfr[0], 16);
+            __builtin_memcpy(&w1, &pfr[1], 16);
+            *LDS_PTR(u32x4, ps) = w0;
+            *LDS_PTR(u32x4, ps + 1024) = w1;
+        };
+        auto dv_gemm = [&](int qb, const vec8 (&pfr)[2]) {   // dV^T[d][key] += dO^T[d][q] P[q][key]
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -286,27 +284,29 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
                     acc[d] = E::mfma(dot, pfr[t2], acc[d]);
                 }
         };
-        f32x16 sacc;
-        // Request order of this wave per tile: [bias block bq+3 (8)] [next Q / dO tile (2*NLD)] ... [bias block bq+4 (8)]; the wait
-        // that ends an iteration leaves only the last 8 in flight, so both blocks read here landed at least one barrier ago and
-        // the counted waits below are no-ops that pin the order. A slot is re-requested right after its reads were issued (the
-        // data of a request arrives hundreds of cycles after the reads have left the LDS queue).
+        // Request order of this wave per tile: [bias block bq+3 (8)] [next Q / dO tile (2*NLD)] [bias block bq+4 (8)]; the wait that
+        // ends an iteration leaves only the last 8 in flight, so both blocks read here landed at least one barrier ago. A slot
+        // is re-requested right after its reads were issued (the data of a request arrives hundreds of cycles after the reads
+        // have left the LDS queue).
         constexpr int slot0 = (2 * buf) % 3, slot1 = (2 * buf + 1) % 3;   // buf = (tq - tq0) % 3
-        if (VBIAS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 + 2 * NLD) : "memory");
+        f32x16 sacc;
+        vec8 pfr[2];
+        auto block = [&](int qb) {
+            s_gemm(qb, sacc);
+            if (need_mask) soft(qb, sacc, pfr, std::true_type{});
+            else soft(qb, sacc, pfr, std::false_type{});
+            dv_gemm(qb, pfr);
+        };
         start(0, slot0, sacc);
-        if (VBIAS) bias_request(r0 + QT + 32, slot0);   // block bq + 3 = second block of the next tile (the reads above were issued first)
+        if (VBIAS) bias_request(r0 + QT + 32, slot0);   // block bq + 3 = second block of the next tile
         if (more) tile_dma(tq + 1, decltype(BN_)::value);
-        if (!skip) block(0, sacc);
-        if (VBIAS) {
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 + 2 * NLD) : "memory");   // (the tile before this one's was waited for at the barrier)
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        }
+        if (!skip) block(0);
         start(1, slot1, sacc);
         if (VBIAS) bias_request(r0 + 2 * QT, slot1);    // block bq + 4 = first block of the tile after the next
-        if (!skip) block(1, sacc);
+        if (!skip) block(1);
     };
 
-    // ---- wave B: one q tile (the one wave A finished in the previous iteration)
+    // ---- wave B: one q tile (the one wave A finished in the previous iteration); straight-line over both row blocks
     auto tile_b = [&](const int tq, auto BUF_, const int pb) {
         constexpr int buf = decltype(BUF_)::value;
         const char* tQ = ldsQ + buf * TILEB;
@@ -314,47 +314,63 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
         const float* tX = ldsDlt + buf * QT;
         bool skip, need_mask;
         classify(tq, skip, need_mask);
-        if (!skip) {
+        if (skip) return;
+        f32x16 pacc[2];
+        u32x4 pw[2][2];
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                f32x16 pacc;
+        for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 c = *LDS_PTR(const f32x4, tX + qb * 32 + 8 * g + 4 * hi);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 c = *LDS_PTR(const f32x4, tX + qb * 32 + 8 * g + 4 * hi);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pacc[4 * g + e] = c[e];
-                }
-                const char* ps = pslot(pb, qb);
-                const u32x4 w0 = *LDS_PTR(const u32x4, ps), w1 = *LDS_PTR(const u32x4, ps + 1024);
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const vec8 da = lds_read_rowfrag<E, D>(tD, qb * 32 + l31, s, hi);
-                    pacc = E::mfma(da, opf[s], pacc);
-                }
-                // dS = P o (dP - delta): P arrives rounded to 16 bit (the value dV was accumulated with)
-                vec8 dsf[2];
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {
-                    const u32x4 w = t2 == 0 ? w0 : w1;
-                    f32x8 x;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const uint32_t word = w[e >> 1];
-                        const float pv = E::to_f32((uint16_t)((e & 1) ? (word >> 16) : (word & 0xffffu)));
-                        x[e] = pv * pacc[8 * t2 + e];
-                    }
-                    dsf[t2] = E::cvt8(x);
-                }
-                // dK^T[d][key] += Q^T[d][q] dS[q][key]
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                    for (int d = 0; d < DB; ++d) {
-                        const vec8 qt = lds_read_trfrag<E, D>(tQ, qb * 32 + 16 * t2, d, lane);
-                        acc[d] = E::mfma(qt, dsf[t2], acc[d]);
-                    }
+                for (int e = 0; e < 4; ++e) pacc[qb][4 * g + e] = c[e];
             }
+            const char* ps = pslot(pb, qb);
+            pw[qb][0] = *LDS_PTR(const u32x4, ps);
+            pw[qb][1] = *LDS_PTR(const u32x4, ps + 1024);
         }
+        auto dp_gemm = [&](int qb) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const vec8 da = lds_read_rowfrag<E, D>(tD, qb * 32 + l31, s, hi);
+                pacc[qb] = E::mfma(da, opf[s], pacc[qb]);
+            }
+        };
+        vec8 dsf[2][2];
+        auto ds_pass = [&](int qb) {   // dS = P o (dP - delta): P arrives rounded to 16 bit (the value dV was accumulated with)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                f32x8 x;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t word = pw[qb][t2][e >> 1];
+                    const float pv = E::to_f32((uint16_t)((e & 1) ? (word >> 16) : (word & 0xffffu)));
+                    x[e] = pv * pacc[qb][8 * t2 + e];
+                }
+                dsf[qb][t2] = E::cvt8(x);
+            }
+        };
+        auto dk_gemm = [&](int qb) {   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const vec8 qt = lds_read_trfrag<E, D>(tQ, qb * 32 + 16 * t2, d, lane);
+                    acc[d] = E::mfma(qt, dsf[qb][t2], acc[d]);
+                }
+        };
+        // scheduling regions pair the MFMAs of one row block with the element pass of the other
+        __builtin_amdgcn_sched_barrier(0);
+        dp_gemm(0);
+        __builtin_amdgcn_sched_barrier(0);
+        dp_gemm(1);
+        ds_pass(0);
+        __builtin_amdgcn_sched_barrier(0);
+        dk_gemm(0);
+        ds_pass(1);
+        __builtin_amdgcn_sched_barrier(0);
+        dk_gemm(1);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // iteration t: A works on tile t, B on tile t-1, tile t+1 is in flight. Buffers relative to tq0; the loop is unrolled by the
@@ -368,13 +384,17 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
         constexpr int ROLE = decltype(ROLE_)::value;
         auto body = [&](const int t, auto BA_, auto BB_, auto BN_) {
             if (ROLE == 0) {
+#ifndef WS_ONLY_B
                 if (t < ntq) tile_a(t, BA_, BN_, (t - tq0) & 1);   // (t == ntq: nothing left to request either)
+#endif
             } else {
                 if (t + 1 < ntq) {
                     tile_dma(t + 1, decltype(BN_)::value);
                     stats_gload((t + 1) * QT);
                 }
+#ifndef WS_ONLY_A
                 if (t > tq0) tile_b(t - 1, BB_, (t - 1 - tq0) & 1);
+#endif
             }
             if (ROLE == 1 && t + 1 < ntq) stats_lstore(decltype(BN_)::value);
             // tile t+1 has landed. Wave A in the bias modes leaves its newest bias request (8 pieces, issued after the tile's) in flight

@@ -601,11 +601,20 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     const float* dltbase = bp.delta + (int64_t)bh * p.Sq;
 
     // query tiles that can see this key block: rows i with i + coff >= first key
-    const int ntq = (p.Sq + QT - 1) / QT;
+    int ntq = (p.Sq + QT - 1) / QT;
     int tq0 = 0;
     if (causal) {
         const int first_row = kblk * BN - coff;
         tq0 = first_row <= 0 ? 0 : first_row / QT;
+    }
+    if (mode_has_keypad(MODE)) {   // a workgroup none of whose keys is visible (the padded tail of a batch element) walks no q-tile at all
+        bool any = false;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int key = kw0 + kb * 32 + l31;
+            any = any || (key < p.Sk && (p.mask == nullptr || p.mask[b * p.ms[0] + h * p.ms[1] + key] != 0));
+        }
+        if (__syncthreads_or(any ? 1 : 0) == 0) ntq = tq0;
     }
 
     // K / V fragments of this wave's keys (B operand: col = key = lane&31, k = 8 contiguous features)
@@ -780,7 +789,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const int key = kw0 + kb * 32 + l31;
-            kp_keep[kb] = key < p.Sk && p.mask[b * p.ms[0] + h * p.ms[1] + key] != 0;
+            kp_keep[kb] = key < p.Sk && (p.mask == nullptr || p.mask[b * p.ms[0] + h * p.ms[1] + key] != 0);
             any = any || kp_keep[kb];
         }
         kp_none = !__any(any);
