@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "fasn_bwd_kernel.h"
 #include "fasn_bwd_dkdv_ws.h"
+#include "fasn_bwd_dq_ws.h"
 #include "fasn_launch.h"
 
 namespace fasn {
@@ -12,7 +13,8 @@ int launch_bwd_d32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d128(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 
-// developer switch (FASN_DEV_VARIANTS builds only): 1 = take the one-wave dK/dV kernel where the two-wave kernel is the default
+// developer switch (FASN_DEV_VARIANTS builds only): bit 0 = take the one-wave dK/dV kernel where the two-wave kernel is the default,
+// bit 1 = the same for dQ
 #ifdef FASN_DEV_VARIANTS
 extern int g_bwd_variant;
 #define FASN_BWD_VARIANT g_bwd_variant
@@ -29,7 +31,19 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         const int64_t rows = (int64_t)nbh * p.f.Sq;
         hipLaunchKernelGGL((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
     }
-    {   // dQ
+    bool dq_done = false;
+    if constexpr (WS != 0 && DROP == 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
+        const int ntiles = (p.f.Sk + KT - 1) / KT;
+        if (!(FASN_BWD_VARIANT & 2) && (!mode_has_keypad(MODE) || ntiles <= kDqWsMaxTiles)) {   // dQ: two cooperating waves per row block
+            constexpr int smem = 5 * KT * D * 2 + 2 * 16384 + (mode_has_vbias(MODE) ? 32768 : 0) + (mode_has_keypad(MODE) ? kDqWsMaxTiles * 8 : 0);
+            p.nblk = (p.f.Sq + 127) / 128;
+            constexpr auto kern = &fasn_bwd_dq_ws_kernel<Tag, D, MODE>;
+            ensure_smem<kern>(smem);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+            dq_done = true;
+        }
+    }
+    if (!dq_done) {   // dQ
         constexpr int BM = 4 * QB * 32;
         constexpr int smem = 4 * KT * D * 2 + (mode_is_vector(MODE) ? 4 * QB * 6144 : 0);   // + per-wave bias / mask images
         p.nblk = (p.f.Sq + BM - 1) / BM;
@@ -38,7 +52,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
     }
     if constexpr (WS != 0 && DROP == 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
-        if (FASN_BWD_VARIANT != 1) {   // dK, dV: two cooperating waves per key block
+        if (!(FASN_BWD_VARIANT & 1)) {   // dK, dV: two cooperating waves per key block
             constexpr int smem = 6 * QT * D * 2 + 2 * 16384 + 6 * QT * 4 + (mode_has_vbias(MODE) ? 4 * 3 * 2048 : 0);
             p.nblk = (p.f.Sk + 127) / 128;
             constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE>;
@@ -75,7 +89,8 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
         case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K, 0, WS>(p, s);
         case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_KEYPAD, OCC_Q, OCC_K, 0, WS>(p, s);   // key-padding mask: plain kernels + visibility bits
         case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1>(p, s);
-        case MODE_BIAS_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 0, WS>(p, s);   // vector bias + visibility bits
+        // vector bias + visibility bits (dQ at D = 128 with two waves per SIMD spills and its 88 KiB of LDS admit one workgroup per CU anyway: 12.7 vs 8.4 ms)
+        case MODE_BIAS_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 0, WS>(p, s);
         case MODE_GENERAL_B:   // bias only: with the two-wave dK/dV kernel the same instantiation without a mask (every key kept)
             if constexpr (WS != 0) return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 0, WS>(p, s);
             else return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1)>(p, s);
