@@ -26,6 +26,9 @@
 #ifndef FASN_UNR3_D128
 #define FASN_UNR3_D128 1
 #endif
+#ifndef FASN_SEED_KEEPALIVE
+#define FASN_SEED_KEEPALIVE 1
+#endif
 #ifndef FASN_FWD_UNR2
 #define FASN_FWD_UNR2 1
 #endif
@@ -167,6 +170,27 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         const int kmax = last_row + coff;  // last visible key of the block
         const int nt_c = kmax < 0 ? 0 : (kmax / KT + 1);
         ntiles = min(ntiles, nt_c);
+    }
+    if (KP && p.mask != nullptr) {
+        // key-padding mask: trailing tiles without a visible key are not walked at all (no staging, no barrier). The workgroup
+        // scans the mask bytes of its key range once, 16 per thread and step (needs a dword-aligned mask row; else no trimming).
+        int* const s_last = reinterpret_cast<int*>(smem + 2 * (RING == 2 ? 3 : 2) * (KT * D * 2) + (mode_is_vector(MODE) ? NW * QB * 6144 : 0));   // 16 spare bytes behind the tiles / images
+        const uint8_t* mrow = p.mask + (b * p.ms[0] + h * p.ms[1]);
+        if ((reinterpret_cast<uintptr_t>(mrow) & 3) == 0) {
+            if (tid == 0) *s_last = -1;
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t mrs16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(mrow), 0, (unsigned)((p.Sk + 3) & ~3), 0x00020000);   // whole dwords: the range check works per dword; bytes past Sk in the last one can only keep a tile
+            int mylast = -1;
+            for (int c = tid; c * 16 < ntiles * KT; c += NT) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(mrs16, c * 16, 0, 0);   // bytes past Sk read as 0
+                if ((w[0] | w[1] | w[2] | w[3]) != 0u) mylast = c >> 2;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mylast = max(mylast, __shfl_xor(mylast, o));
+            if (lane == 0 && mylast >= 0) atomicMax(s_last, mylast);
+            __syncthreads();
+            ntiles = min(ntiles, *s_last + 1);
+        }
     }
     const int t_begin = SPLIT ? split * p.tps : 0;   // tps is a multiple of 6: t & 1 and t % 3 select the LDS buffer as if t started at 0
     if (SPLIT) ntiles = min(ntiles, t_begin + p.tps);
@@ -519,6 +543,14 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 }
             }
 
+            // keep the -m tuple visibly alive past the QK^T MFMAs: the compiler then uses it as an UNTIED C operand for every key
+            // block's first MFMA instead of copying it into the second block's accumulator (16 v_mov_b64 per 64-row tile)
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass cannot take a 16-register tuple as an asm operand)
+            if (SEED && !VEC && FASN_SEED_KEEPALIVE) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) asm volatile("" ::"v"(mseed[qb]));
+            }
+#endif
             if (PRIO == 3 && NW == 4) __builtin_amdgcn_s_setprio(0);
 
             // dropout of the 8 weights of (qb, kb, t2): keys k0 + kb*32 + 16*t2 + 4*hi + {0..3} and + 8 + {0..3}

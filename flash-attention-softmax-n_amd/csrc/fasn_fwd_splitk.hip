@@ -11,7 +11,7 @@ int launch_splitk_one(FwdParams p, hipStream_t s) {
     // D = 128: register staging, two LDS buffers, so that two workgroups (2 x 64 KiB) fit on a CU
     constexpr int RING = (D == 128 && MODE != MODE_GENERAL) ? 0 : 2;   // (the D = 128 mask/bias kernel spills with staging registers)
     constexpr int OCC = 2;
-    constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2 + (MODE == MODE_GENERAL ? 4 * 6144 : 0);
+    constexpr int smem = fwd_smem(D, RING, MODE, 4, 1);
     p.nqblk = (p.Sq + BM - 1) / BM;
     constexpr auto kern = &fasn_fwd_kernel<Tag, D, 1, MODE, OCC, 4, 0, 0, 0, RING, 1>;
     ensure_smem<kern>(smem);

@@ -44,7 +44,7 @@ inline int launch_rc() { return hipGetLastError() == hipSuccess ? 0 : -6; }
 
 constexpr bool mode_is_vec(int MODE) { return mode_is_vector(MODE); }
 constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB) {
-    return (RING == 2 ? 6 : 4) * KT * D * 2 + (mode_is_vec(MODE) ? NW * QB * 6144 : 0);   // K/V buffers + per-wave bias / mask images
+    return (RING == 2 ? 6 : 4) * KT * D * 2 + (mode_is_vec(MODE) ? NW * QB * 6144 : 0) + 16;   // K/V buffers + per-wave bias / mask images + scratch word
 }
 
 // one instantiation of the forward kernel: NW waves x QB 32-row blocks per wave, staging scheme RING, accumulator seeding SEED
@@ -125,7 +125,7 @@ int launch_fwd_abl8(const FwdParams& p, hipStream_t s) { return launch_fwd_abl<T
 template <typename Tag, int D, int QB, int MODE, int OCC, int RING = 1, int PRIO = 0, int SEED = 0, int NW = 4>
 int launch_fwd_ring_one(FwdParams p, hipStream_t s) {
     constexpr int BM = NW * QB * 32;
-    constexpr int smem = (RING == 2 ? 6 : 4) * KT * D * 2;
+    constexpr int smem = fwd_smem(D, RING, MODE, NW, QB);
     p.nqblk = (p.Sq + BM - 1) / BM;
     constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, PRIO, 0, 0, RING, 0, SEED>;
     ensure_smem<kern>(smem);
