@@ -405,6 +405,38 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, t_begin * KT, 0);   // keys past Sk read as hidden
     }
 
+    // Direct-to-LDS vector kernels (LATE): the image of a tile is moved LDS -> registers at the END of the tile before, between
+    // the wait that precedes the barrier and the barrier itself, and the image after it is requested there: the LDS latency
+    // and the request instructions then sit where the wave waits for its neighbours anyway instead of in front of the tile's
+    // first MFMA (both waves of a SIMD belong to one workgroup and run in phase, so nothing else covered them there).
+    constexpr bool LATE = VEC && RING == 2;
+    uint32_t mraw_c[QB][2][4];
+    u32x2 braw_c[QB][2][4];
+    auto image_to_regs = [&](uint32_t (&mr)[QB][2][4], u32x2 (&br)[QB][2][4]) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (VBIAS) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const u32x4 w = *LDS_PTR(const u32x4, ldsGB + qb * 4096 + tile_off<64>(l31, kb * 4 + 2 * hi + j));
+                        br[qb][kb][2 * j] = u32x2{w[0], w[1]};
+                        br[qb][kb][2 * j + 1] = u32x2{w[2], w[3]};
+                    }
+                }
+                if (VMASK) {
+                    const u32x4 w = *LDS_PTR(const u32x4, ldsGM + qb * 2048 + tile_off<32>(l31, kb * 2 + hi));
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mr[qb][kb][g] = w[g];
+                }
+            }
+    };
+    if (LATE && ntiles > t_begin) {   // (the prologue's wait and barrier above published the first image)
+        image_to_regs(mraw_c, braw_c);
+        gen_dma(t_begin + 1);
+    }
+
     // one K/V tile; LSET = register set that receives the prefetch issued here, SSET = set written to LDS at the end
     auto tile_body = [&](const int t, auto LSET, auto SSET) {
         // RING 1: the loop is unrolled by two (even tile: LSET = set 0, odd tile: LSET = set 1), so the LDS buffer index is a
@@ -442,33 +474,26 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         uint32_t mraw[QB][2][4];
         u32x2 braw[QB][2][4];
         if (SLOW) need_mask = true;
-        if (VEC) {   // unconditional (also for skipped tiles): the request / wait pattern stays the same for every tile
-            // this tile's bias / mask image has landed (RING 2: the K/V tile requested last stays in flight)
-            if (RING == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (LATE) {   // the image is already in registers (end of the previous tile); only the requests of this tile remain
+            if (KP) kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
+            stage_direct(t + 2, buf2);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    if (VBIAS) {
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const u32x4 w = *LDS_PTR(const u32x4, ldsGB + qb * 4096 + tile_off<64>(l31, kb * 4 + 2 * hi + j));
-                            braw[qb][kb][2 * j] = u32x2{w[0], w[1]};
-                            braw[qb][kb][2 * j + 1] = u32x2{w[2], w[3]};
-                        }
+                    for (int g = 0; g < 4; ++g) {
+                        braw[qb][kb][g] = braw_c[qb][kb][g];
+                        mraw[qb][kb][g] = mraw_c[qb][kb][g];
                     }
-                    if (VMASK) {
-                        const u32x4 w = *LDS_PTR(const u32x4, ldsGM + qb * 2048 + tile_off<32>(l31, kb * 2 + hi));
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) mraw[qb][kb][g] = w[g];
-                    }
-                }
+        } else if (VEC) {   // unconditional (also for skipped tiles): the request / wait pattern stays the same for every tile
+            // this tile's bias / mask image has landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            image_to_regs(mraw, braw);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before the next one is requested
             if (KP) kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
             gen_dma(t + 1);                                        // past-the-end tiles are out of range: zeros
-            if (RING == 2) stage_direct(t + 2, buf2);
-            else stage_load(t + 1 + RING, LSET);
+            stage_load(t + 1 + RING, LSET);
         }
         if (!skip) {
             const char* tK = ldsK + buf * TILEB;
@@ -752,7 +777,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         }
 
         if (RING == 2) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile t+1 is in LDS, tile t+2 still in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile t+1 (and its image) is in LDS, tile t+2 still in flight
+            if (LATE) {   // next tile's image -> registers, the one after it requested (its data arrives long after these reads left the LDS queue)
+                image_to_regs(mraw_c, braw_c);
+                gen_dma(t + 2);
+            }
             __syncthreads();
         } else if (ABL != 6 && ABL != 7) {
             if (ABL != 8 && (VEC || RING || t + 1 < ntiles)) stage_store(buf ^ 1, SSET);
