@@ -10,14 +10,14 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasn.so")
 
-FASN_ABI_VERSION = 2
+FASN_ABI_VERSION = 3
 FASN_DTYPE_F16, FASN_DTYPE_BF16, FASN_DTYPE_F32 = 0, 1, 2
 FASN_BIAS_NONE, FASN_BIAS_SAME, FASN_BIAS_F32 = 0, 1, 2
 
 # every entry point include/fasn.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "fasn_abi_version", "fasn_strerror", "fasn_supported", "fasn_fwd", "fasn_fwd_workspace_bytes", "fasn_fwd_ws",
-    "fasn_bwd_workspace_bytes", "fasn_bwd",
+    "fasn_bwd_workspace_bytes", "fasn_bwd", "fasn_rng_advance",
     "fasn_softmax_n_fwd", "fasn_softmax_n_bwd", "fasn_moments",
 )
 
@@ -36,6 +36,7 @@ class FwdArgs(Structure):
         ("scale", c_float), ("softmax_n", c_float), ("causal", c_int32), ("dropout_p", c_float),
         ("seed", c_uint64), ("offset", c_uint64),
         ("kv_group", c_int32),
+        ("rng_state", c_void_p),
     ]
 
 
@@ -81,6 +82,8 @@ def load():
     lib.fasn_fwd_ws.argtypes = [POINTER(FwdArgs), c_void_p, c_size_t, c_void_p]
     lib.fasn_bwd.restype = c_int32
     lib.fasn_bwd.argtypes = [POINTER(BwdArgs), c_void_p]
+    lib.fasn_rng_advance.restype = c_int32
+    lib.fasn_rng_advance.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
     lib.fasn_bwd_workspace_bytes.restype = c_size_t
     lib.fasn_bwd_workspace_bytes.argtypes = [POINTER(BwdArgs)]
     lib.fasn_softmax_n_fwd.restype = c_int32

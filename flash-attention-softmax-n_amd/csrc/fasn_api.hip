@@ -100,17 +100,19 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
         p.bias_bytes = (unsigned)((bb + 3) & ~3ll);
         p.mask_bytes = (unsigned)((mb + 3) & ~3ll);
     }
-    // dropout: 8-bit threshold, drop probability thr/256 (the nearest representable value to dropout_p, at least 1/256)
+    // dropout: 16-bit threshold, drop probability thr/65536 (the nearest representable value to dropout_p, at least 1/65536)
     p.drop_thr = 0;
     p.drop_scale = 1.f;
     if (a->dropout_p > 0.f) {
-        int thr = (int)lrintf(a->dropout_p * 256.f);
-        thr = thr < 1 ? 1 : (thr > 255 ? 255 : thr);
+        long thr = lrintf(a->dropout_p * 65536.f);
+        thr = thr < 1 ? 1 : (thr > 65535 ? 65535 : thr);
         p.drop_thr = (unsigned)thr;
-        p.drop_scale = 256.f / (256.f - (float)thr);
+        p.drop_scale = 65536.f / (65536.f - (float)thr);
     }
-    p.seed_lo = (unsigned)(a->seed & 0xffffffffu) ^ (unsigned)(a->offset * 0x9E3779B1u);
+    p.seed_lo = (unsigned)(a->seed & 0xffffffffu) ^ ((unsigned)a->offset * 0x9E3779B1u);
     p.seed_hi = (unsigned)(a->seed >> 32) + (unsigned)(a->offset >> 32);
+    p.rng = a->rng_state;   // device {seed, offset}: overrides the two by-value words when given
+    if (a->rng_state != nullptr && reinterpret_cast<uintptr_t>(a->rng_state) % 8) return FASN_EALIGN;
     p.c = a->scale * kLog2e;
     {
         // extent of one (b,h) matrix = last row start + one row (a length-1 sequence may carry stride 0)
@@ -186,9 +188,26 @@ int dispatch_fwd(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 
 }  // namespace
 
+namespace {
+__global__ void rng_advance_kernel(uint64_t* state, uint64_t* out, uint64_t increment) {
+    const uint64_t s = state[0], o = state[1];
+    if (out != nullptr) {
+        out[0] = s;
+        out[1] = o;
+    }
+    state[1] = o + increment;
+}
+}  // namespace
+
 extern "C" {
 
 int fasn_abi_version(void) { return FASN_ABI_VERSION; }
+
+int fasn_rng_advance(uint64_t* state, uint64_t* out, uint64_t increment, fasn_stream_t stream) {
+    if (state == nullptr || reinterpret_cast<uintptr_t>(state) % 8 || reinterpret_cast<uintptr_t>(out) % 8) return FASN_EINVAL;
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, out, increment);
+    return hipGetLastError() == hipSuccess ? FASN_OK : FASN_ELAUNCH;
+}
 
 const char* fasn_strerror(int code) {
     switch (code) {

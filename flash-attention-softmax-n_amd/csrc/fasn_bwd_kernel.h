@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int hi = lane >> 5;
+    const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
 
     int bh, qi;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
@@ -465,8 +466,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                             if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                             float dp = pacc[qb][r];
                             if (DROP) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
-                                const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row);
-                                const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)((k0 + kb * 32 + (VEC ? 16 * hi + 4 * (r >> 2) : 8 * (r >> 2) + 4 * hi)) >> 2));
+                                const uint32_t rb = drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row);
+                                const u32x2 hsh = drop_hash(rb, dsd.hi, (uint32_t)((k0 + kb * 32 + (VEC ? 16 * hi + 4 * (r >> 2) : 8 * (r >> 2) + 4 * hi)) >> 2));
                                 dp = drop_keep(hsh, r & 3, p.drop_thr) ? dp * p.drop_scale : 0.f;
                             }
                             sacc[qb][r] = SEED_P ? pv * dp : pv * (dp - dlt[qb]);
@@ -585,6 +586,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int hi = lane >> 5;
+    const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
 
     int bh, kblk;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
@@ -913,9 +915,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                         float pd = pv;
                         if (DROP) {   // lane = key here: one hash per element, byte (key & 3) of the (row, key>>2) hash
                             const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row);
-                            const uint32_t hsh = drop_hash(rb, p.seed_hi, (uint32_t)(key >> 2));
-                            const bool keep = ((hsh >> (8 * (key & 3))) & 0xffu) >= p.drop_thr;
+                            const uint32_t rb = drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row);
+                            const u32x2 hsh = drop_hash(rb, dsd.hi, (uint32_t)(key >> 2));
+                            const bool keep = drop_keep(hsh, key & 3, p.drop_thr);
                             dp = keep ? dp * p.drop_scale : 0.f;
                             pd = keep ? pv * p.drop_scale : 0.f;
                         }

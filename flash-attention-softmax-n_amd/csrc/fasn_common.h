@@ -185,23 +185,42 @@ FASN_DEV void retire_loads(V& v) {
 }
 
 // ---- dropout -------------------------------------------------------------------------------------------------------
-// Counter-based, layout-independent: the keep/drop decision of attention weight (bh, row i, key j) is byte (j & 3) of
-// a 32-bit hash of (seed, bh, i, j >> 2); the weight is kept iff byte >= thr (drop probability thr/256). Every kernel
-// (forward and both backward kernels, which hold the score tile in different register layouts) recomputes the same bits.
-// Mirror on the host: flash-attention-softmax-n_amd/dropout.py (used by the tests to build the explicit mask).
+// Counter-based, layout-independent: the keep/drop decision of attention weight (bh, row i, key j) is the 16-bit field (j & 3)
+// of a 64-bit hash of (seed, offset, bh, i, j >> 2); the weight is kept iff field >= thr (drop probability thr / 65536, so a
+// requested p is honoured to 1.5e-5). Every kernel (forward and both backward kernels, which hold the score tile in different
+// register layouts) recomputes the same bits. Mirror on the host: flash-attention-softmax-n_amd/dropout.py (the tests build
+// the explicit mask for the oracle with it).
+// The (seed, offset) pair comes by value in the launch parameters or - when the caller passes a device pointer - from two
+// 64-bit words in device memory that a captured graph can advance between replays (fasn_rng_advance).
+struct DropSeed {
+    uint32_t lo, hi;
+};
+FASN_DEV DropSeed drop_seed(uint32_t seed_lo, uint32_t seed_hi, const uint64_t* rng) {
+    DropSeed d{seed_lo, seed_hi};
+    if (rng != nullptr) {   // same folding as the host side (fasn_api.hip: build_fwd)
+        const uint64_t s = rng[0], o = rng[1];
+        d.lo = (uint32_t)s ^ ((uint32_t)o * 0x9E3779B1u);
+        d.hi = (uint32_t)(s >> 32) + (uint32_t)(o >> 32);
+    }
+    d.lo = __builtin_amdgcn_readfirstlane(d.lo);
+    d.hi = __builtin_amdgcn_readfirstlane(d.hi);
+    return d;
+}
 FASN_DEV uint32_t drop_row_base(uint32_t seed_lo, uint32_t bh, uint32_t row) {
     return (seed_lo ^ (bh * 0x9E3779B1u)) + row * 0x85EBCA77u;
 }
-FASN_DEV uint32_t drop_hash(uint32_t row_base, uint32_t seed_hi, uint32_t key_quad) {
+FASN_DEV u32x2 drop_hash(uint32_t row_base, uint32_t seed_hi, uint32_t key_quad) {
     uint32_t x = row_base ^ (key_quad * 0xC2B2AE3Du + seed_hi);
     x ^= x >> 16;
     x *= 0x7feb352du;
     x ^= x >> 15;
-    x *= 0x846ca68bu;
-    x ^= x >> 16;
-    return x;
+    uint32_t lo = x * 0x846ca68bu;
+    uint32_t hi = lo * 0x9E3779B1u;   // second word: one more multiply-fold of the first (every 16-bit field uniform)
+    hi ^= hi >> 15;
+    lo ^= lo >> 16;
+    return u32x2{lo, hi};
 }
-FASN_DEV bool drop_keep(uint32_t hash, int e, uint32_t thr) { return ((hash >> (8 * e)) & 0xffu) >= thr; }
+FASN_DEV bool drop_keep(u32x2 hash, int e, uint32_t thr) { return ((hash[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= thr; }
 
 FASN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 

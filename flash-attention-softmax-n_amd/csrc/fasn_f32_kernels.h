@@ -78,7 +78,8 @@ struct GenElem {
     }
 };
 FASN_DEV bool f32_keep(const FwdParams& p, int bh, int row, int key) {
-    const uint32_t hsh = drop_hash(drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)row), p.seed_hi, (uint32_t)(key >> 2));
+    const DropSeed dsd = drop_seed(p.seed_lo, p.seed_hi, p.rng);
+    const u32x2 hsh = drop_hash(drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row), dsd.hi, (uint32_t)(key >> 2));
     return drop_keep(hsh, key & 3, p.drop_thr);
 }
 

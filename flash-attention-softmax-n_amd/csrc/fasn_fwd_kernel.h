@@ -66,9 +66,10 @@ struct FwdParams {
     int batch_inner;  // bias/mask broadcast over batch: schedule the batch innermost so a head's bias tile is reused from L2
     unsigned kbytes, vbytes;  // byte extent of one (b,h) K / V matrix: Sk * row_stride * 2 (buffer descriptor range)
     unsigned bias_bytes, mask_bytes;  // byte extent of one (b,h) bias / mask slice: (Sq-1)*row_stride + Sk elements
-    unsigned drop_thr;        // dropout: drop an attention weight iff its hash byte < drop_thr (0 = no dropout)
+    unsigned drop_thr;        // dropout: drop an attention weight iff its 16-bit hash field < drop_thr (0 = no dropout)
     unsigned seed_lo, seed_hi;
-    float drop_scale;         // 256 / (256 - drop_thr): applied to O (and to dP in the backward)
+    const uint64_t* rng;      // optional device {seed, offset}: replaces seed_lo / seed_hi (graph-safe dropout state)
+    float drop_scale;         // 65536 / (65536 - drop_thr): applied to O (and to dP in the backward)
     float c;        // scale * log2(e)
     float n;        // softmax_n
     // split-K (SPLIT kernels, short query / long key "decode" shapes): the keys of one (b,h, query block) are divided over
@@ -262,6 +263,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         }
     };
 
+    const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
     // ---- online-softmax state, per lane = per query row (log2 domain: y = x * log2(e))
     float m_run[QB], l_run[QB];
     f32x16 oacc[QB][DB];
@@ -580,11 +582,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 
             // dropout of the 8 weights of (qb, kb, t2): keys k0 + kb*32 + 16*t2 + 4*hi + {0..3} and + 8 + {0..3}
             auto drop8 = [&](f32x8& x, int qb, int kb, int t2) {
-                const uint32_t rb = drop_row_base(p.seed_lo, (uint32_t)bh, (uint32_t)(qw0 + qb * 32 + l31));
+                const uint32_t rb = drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)(qw0 + qb * 32 + l31));
                 // registers 8*t2 + {0..3} and + {4..7} are two groups of 4 consecutive keys: 8 apart in the plain layout,
                 // adjacent in the key-permuted layout of the vector general modes
                 const uint32_t kq = (uint32_t)((k0 + kb * 32 + (KPERM ? 16 * hi + 8 * t2 : 16 * t2 + 4 * hi)) >> 2);
-                const uint32_t h0 = drop_hash(rb, p.seed_hi, kq), h1 = drop_hash(rb, p.seed_hi, kq + (KPERM ? 1 : 2));
+                const u32x2 h0 = drop_hash(rb, dsd.hi, kq), h1 = drop_hash(rb, dsd.hi, kq + (KPERM ? 1 : 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     x[e] = drop_keep(h0, e, p.drop_thr) ? x[e] : 0.f;

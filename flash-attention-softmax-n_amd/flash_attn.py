@@ -53,7 +53,39 @@ def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p=0.0, seed=0, offset=0):
+# ---- dropout stream (reference: torch's philox generator behind core/flash_attn.py:122 and core/functional.py:92) ----
+# One {seed, offset} pair per device lives IN DEVICE MEMORY. Every dropout call takes its own copy of the pair and advances the
+# offset with one tiny kernel on the launch stream (fasn_rng_advance): no host synchronisation, and a captured HIP graph that
+# contains the call draws a fresh mask on every replay. The pair is (re)initialised from torch's CUDA generator of the device
+# - seed = its initial_seed(), offset = its philox offset - whenever that generator was re-seeded (torch.manual_seed), so
+# seeded runs are reproducible; the generator's own offset is advanced as well, as any torch random op would.
+_RNG_STATE = {}
+
+
+def _next_rng_state(device) -> Tensor:
+    """int64[2] device tensor {seed, offset} for ONE forward call (its backward reads the same tensor)."""
+    lib = _lib.load()
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    capturing = torch.cuda.is_current_stream_capturing()
+    st = _RNG_STATE.get(idx)
+    if not capturing:
+        gen = torch.cuda.default_generators[idx]
+        seed, off = gen.initial_seed(), gen.get_offset()
+        if st is None or st["seed"] != seed or off < st["torch_offset"]:   # first use, or the generator was re-seeded
+            state = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, off], dtype=torch.int64, device=device)
+            st = _RNG_STATE[idx] = {"seed": seed, "state": state, "torch_offset": off}
+        gen.set_offset(off + 4)
+        st["torch_offset"] = off + 4
+    elif st is None:
+        raise RuntimeError("dropout inside a HIP graph capture: run one dropout call on this device before capturing "
+                           "(the device-side random state is created on first use)")
+    out = torch.empty(2, dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.fasn_rng_advance(st["state"].data_ptr(), out.data_ptr(), 1, _stream_ptr(device)), "fasn_rng_advance")
+    return out
+
+
+def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p=0.0, seed=0, offset=0, rng=None):
     a.q, a.k, a.v, a.o = _view4(q), _view4(k), _view4(v), _view4(o)
     a.lse = lse.data_ptr()
     a.mask = _view4(mask)
@@ -73,19 +105,20 @@ def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal, dropout
     a.dropout_p = dropout_p
     a.seed = seed
     a.offset = offset
+    a.rng_state = None if rng is None else rng.data_ptr()
 
 
 class _FlashAttentionSoftmaxN(torch.autograd.Function):
     """autograd glue; same role as _FlashAttentionN (flash_attn_triton.py:241-336)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, bias, n: float, scale: float, causal: bool, dropout_p: float = 0.0, seed: int = 0):
+    def forward(ctx, q, k, v, mask, bias, n: float, scale: float, causal: bool, dropout_p: float = 0.0, rng: Optional[Tensor] = None):
         lib = _lib.load()
         B, H, L, D = q.shape
         o = torch.empty((B, H, L, v.shape[3]), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
         a = FwdArgs()
-        _fill_fwd(a, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p, seed, 0)
+        _fill_fwd(a, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p, 0, 0, rng)
         with torch.cuda.device(q.device):
             ws_bytes = lib.fasn_fwd_workspace_bytes(a)   # > 0: short-query / long-key shape, keys split over workgroups
             if ws_bytes:
@@ -94,7 +127,7 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
             else:
                 _lib.check(lib.fasn_fwd(a, _stream_ptr(q.device)), "fasn_fwd")
         ctx.save_for_backward(q, k, v, o, lse, mask, bias)
-        ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, ctx.seed = n, scale, causal, dropout_p, seed
+        ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, ctx.rng = n, scale, causal, dropout_p, rng
         return o
 
     @staticmethod
@@ -110,7 +143,7 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         dv = torch.empty((B, H, S, v.shape[3]), dtype=q.dtype, device=q.device)
         delta = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
         a = BwdArgs()
-        _fill_fwd(a.fwd, q, k, v, o, lse, mask, bias, ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, ctx.seed, 0)
+        _fill_fwd(a.fwd, q, k, v, o, lse, mask, bias, ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, 0, 0, ctx.rng)
         a.dout, a.dq, a.dk, a.dv = _view4(dout), _view4(dq), _view4(dk), _view4(dv)
         a.delta = delta.data_ptr()
         a.workspace = None
@@ -198,11 +231,10 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
             bias = bias.to(query.dtype)
         bias = bias.expand(B, H, L, S)
 
-    seed = 0
-    if dropout_p > 0.0:
-        # one 63-bit seed per call from torch's CPU generator (honours torch.manual_seed); the kernels derive every
-        # keep/drop bit from (seed, b, h, row, key) — see dropout.py for the host mirror
-        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    # dropout: this call's {seed, offset} in device memory (see _next_rng_state); the kernels derive every keep/drop bit from
+    # (seed, offset, b, h, row, key) - dropout.py is the host mirror
+    rng = _next_rng_state(query.device) if dropout_p > 0.0 else None
+    _attention.last_rng_state = rng
     Hkv = k.shape[1]
     if L == 1 and Hkv != H and dropout_p == 0.0:
         # grouped-query decode: the G query heads of a group become G query ROWS of one problem per K/V head, so each K/V head
@@ -215,13 +247,21 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
         except RuntimeError:      # strides that cannot be regrouped without a copy: keep the per-head launch
             mask_g = bias_g = False
         if mask_g is not False:
-            out = _FlashAttentionSoftmaxN.apply(q.view(B, Hkv, G, dpad), k, v, mask_g, bias_g, n, scale, False, 0.0, 0)
+            out = _FlashAttentionSoftmaxN.apply(q.view(B, Hkv, G, dpad), k, v, mask_g, bias_g, n, scale, False, 0.0, None)
             out = out.view(B, H, 1, dpad)
-            _attention.last_seed = 0
             return out if Ev == dpad else out[..., :Ev]
-    out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, seed)
-    _attention.last_seed = seed
+    out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, rng)
     return out if Ev == dpad else out[..., :Ev]
+
+
+def last_dropout_state():
+    """(seed, offset) of the most recent dropout call as Python ints (one device read), for dropout.keep_mask; None if that call
+    had dropout_p == 0. Test / reproduction helper."""
+    t = getattr(_attention, "last_rng_state", None)
+    if t is None:
+        return None
+    s, o = (int(x) for x in t.cpu().tolist())
+    return s & 0xFFFFFFFFFFFFFFFF, o & 0xFFFFFFFFFFFFFFFF
 
 
 def flash_attention_n(
@@ -243,7 +283,9 @@ def flash_attention_n(
     :param value: [B, H, S, Ev].
     :param softmax_n_param: n >= 0; real values allowed (the reference's SDPA path takes integers only).
     :param scale: multiplies q.k^T; default 1/sqrt(E).
-    :param dropout_p: attention-weight dropout, realised in 1/256 steps (dropout.effective_p); mask regenerated in backward.
+    :param dropout_p: attention-weight dropout, realised in 1/65536 steps (dropout.effective_p); the mask is a pure function of
+                      the call's (seed, offset) - drawn from a per-device stream seeded by torch's CUDA generator, advanced on the
+                      device so that HIP-graph replays resample - and regenerated in backward.
     :param attn_mask: bool, 4-D, broadcastable to [B, H, L, S]; True = attend.
     :param attn_bias: additive bias [H, L, S] or broadcastable to [B, H, L, S] (e.g. ALiBi); not differentiated.
     :param is_causal: bottom-right aligned causal mask (key j visible to row i iff j <= i + S - L).

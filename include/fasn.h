@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FASN_ABI_VERSION 2
+#define FASN_ABI_VERSION 3
 
 /* error codes */
 #define FASN_OK 0
@@ -83,12 +83,16 @@ typedef struct fasn_fwd_args {
     float scale;        /* multiplies q.k before bias (reference default 1/sqrt(D)) */
     float softmax_n;    /* n >= 0, real-valued */
     int32_t causal;     /* bottom-right aligned: key j visible to row i iff j <= i + Sk - Sq */
-    float dropout_p;    /* in [0,1): attention-weight dropout; realised as thr/256 with thr = round(256 p) in [1,255] */
+    float dropout_p;    /* in [0,1): attention-weight dropout; realised as thr/65536 with thr = round(65536 p) in [1,65535] */
     uint64_t seed, offset; /* dropout stream: the keep bit of (b,h,row,key) is a pure function of (seed, offset, indices);
                               pass the SAME values to fasn_bwd (see flash-attention-softmax-n_amd/dropout.py) */
     int32_t kv_group;      /* grouped-query attention (ABI 2): query head h reads K/V head h / kv_group, i.e. k and v are
                               [B, H / kv_group, Sk, D] addressed through their head stride; 0 or 1 = one K/V head per query
                               head. fasn_bwd still writes dk / dv per QUERY head [B,H,Sk,D]; the caller sums each group. */
+    const uint64_t* rng_state; /* optional (ABI 3): DEVICE pointer to {seed, offset} (8-byte aligned). When set, the kernels read the
+                              dropout stream position from device memory instead of `seed` / `offset` above, so a captured HIP graph
+                              that also captures fasn_rng_advance() draws a fresh mask on every replay. Pass the same pointer (and the
+                              same contents) to fasn_bwd. NULL = use the by-value fields. */
 } fasn_fwd_args;
 
 /*
@@ -127,6 +131,14 @@ int fasn_fwd(const fasn_fwd_args* args, fasn_stream_t stream);
  */
 size_t fasn_fwd_workspace_bytes(const fasn_fwd_args* args);
 int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_bytes, fasn_stream_t stream);
+
+/*
+ * Dropout stream position in device memory (replaces the host-side philox seed / offset bookkeeping behind
+ * flash_attention_softmax_n/core/flash_attn.py:122 and functional.py:92): copies state[0..1] = {seed, offset} to out[0..1]
+ * (out may be NULL) and advances state[1] by `increment`, as one tiny kernel on `stream` - capturable, no host round trip.
+ * A forward call takes `out` as its rng_state; the backward of that call gets the same `out`.
+ */
+int fasn_rng_advance(uint64_t* state, uint64_t* out, uint64_t increment, fasn_stream_t stream);
 
 size_t fasn_bwd_workspace_bytes(const fasn_bwd_args* args);
 int fasn_bwd(const fasn_bwd_args* args, fasn_stream_t stream);

@@ -38,7 +38,7 @@ def test_library_exports_nothing_but_the_header(pkg):
 
 def test_abi_version_and_strerror(pkg):
     lib = pkg._lib.load()
-    assert lib.fasn_abi_version() == 2
+    assert lib.fasn_abi_version() == 3
     assert lib.fasn_strerror(0) == b"ok"
     for code in range(-8, 0):
         assert len(lib.fasn_strerror(code)) > 5
@@ -141,7 +141,8 @@ def test_synth_is_index_addressable_and_deterministic(pkg):
 
 def test_dropout_host_mirror_statistics(pkg):
     d = pkg.dropout
-    assert d.threshold(0.0) == 0 and d.threshold(0.2) == 51 and d.threshold(1e-4) == 1 and d.threshold(0.9999) == 255
+    assert d.threshold(0.0) == 0 and d.threshold(0.2) == 13107 and d.threshold(1e-6) == 1 and d.threshold(0.99999) == 65535
+    assert abs(d.effective_p(0.1) - 0.1) < 1.6e-5
     keep = d.keep_mask(7, 0, 2, 2, 128, 256, 0.25)
     assert keep.shape == (2, 2, 128, 256) and abs((1 - keep.mean()) - 0.25) < 0.01
     assert (d.keep_mask(7, 0, 2, 2, 128, 256, 0.25) == keep).all() and (d.keep_mask(8, 0, 2, 2, 128, 256, 0.25) != keep).any()

@@ -451,7 +451,7 @@ def test_fp32_mask_bias_dropout(pkg, dev, kind, D):
     assert out.dtype == torch.float32
     out.backward(do)
     if p:
-        keep = pkg.dropout.keep_mask(pkg.flash_attn._attention.last_seed, 0, B, H, L, S, p)
+        keep = pkg.dropout.keep_mask(*pkg.flash_attn.last_dropout_state(), B, H, L, S, p)
         o, dq, dk, dv = _oracle_dropout(q, k, v, do, keep, pkg.dropout.effective_p(p), softmax_n_param=0.5, is_causal=causal,
                                         attn_mask=mask.cpu(), attn_bias=bias.cpu())
     else:
@@ -500,10 +500,11 @@ def test_dropout_matches_oracle_with_explicit_mask(pkg, dev, D, mode, dtype):
         mask = synth.keypad_mask(B, S, device=dev)
     torch.manual_seed(1234)
     out = pkg.flash_attention_n(q, k, v, dropout_p=p, attn_mask=mask, attn_bias=bias, **kw)
-    seed = pkg.flash_attn._attention.last_seed
+    seed, offset = pkg.flash_attn.last_dropout_state()
     out.backward(do)
-    keep = pkg.dropout.keep_mask(seed, 0, B, H, L, S, p)
+    keep = pkg.dropout.keep_mask(seed, offset, B, H, L, S, p)
     p_eff = pkg.dropout.effective_p(p)
+    assert abs(p_eff - p) < 1.6e-5            # 16-bit threshold: the requested probability is honoured to 2^-16
     assert abs((1.0 - keep.mean()) - p_eff) < 0.01
     o, dq, dk, dv = _oracle_dropout(q, k, v, do, keep, p_eff, attn_mask=None if mask is None else mask.cpu(),
                                     attn_bias=None if bias is None else bias.float().cpu(), **kw)
@@ -530,6 +531,57 @@ def test_dropout_reference_grid_is_finite_and_unbiased(pkg, dev):
     for i in range(16):
         acc += pkg.flash_attention_n(q, k, v, softmax_n_param=1, dropout_p=0.2).float()
     assert (acc / 16 - base).abs().max().item() < 0.25 * base.abs().max().item() + 0.01
+
+
+def test_dropout_stream_follows_the_torch_generator_and_resamples_in_graph_replays(pkg, dev):
+    """The (seed, offset) of a call comes from a per-device stream in DEVICE memory seeded by torch's CUDA generator
+    (reference: torch's philox state behind core/flash_attn.py:122): re-seeding reproduces the sequence, consecutive calls differ,
+    and a captured forward + backward draws a fresh mask on every replay - each replay still matching the host mirror."""
+    dtype = torch.bfloat16
+    B, H, L, S, D, p = 2, 2, 128, 192, 64, 0.1
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    torch.manual_seed(99)
+    a1 = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, dropout_p=p)
+    s1 = pkg.flash_attn.last_dropout_state()
+    a2 = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, dropout_p=p)
+    s2 = pkg.flash_attn.last_dropout_state()
+    assert s1[0] == 99 and s2[0] == 99 and s2[1] == s1[1] + 1 and not torch.equal(a1, a2)
+    torch.manual_seed(99)
+    b1 = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, dropout_p=p)
+    assert pkg.flash_attn.last_dropout_state() == s1 and torch.equal(a1, b1)
+    torch.manual_seed(100)
+    c1 = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, dropout_p=p)
+    assert pkg.flash_attn.last_dropout_state()[0] == 100 and not torch.equal(a1, c1)
+
+    # graph: capture forward + backward once, replay three times
+    sq, sk, sv = (t.detach().clone().requires_grad_() for t in (q, k, v))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):   # warm-up outside the capture (allocations, device random state)
+            o = pkg.flash_attention_n(sq, sk, sv, softmax_n_param=1.0, dropout_p=p)
+            o.backward(do)
+            sq.grad = sk.grad = sv.grad = None
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        go = pkg.flash_attention_n(sq, sk, sv, softmax_n_param=1.0, dropout_p=p)
+        state_t = pkg.flash_attn._attention.last_rng_state
+        go.backward(do)
+    outs, states = [], []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        outs.append((go.detach().clone(), sq.grad.detach().clone(), sk.grad.detach().clone(), sv.grad.detach().clone()))
+        states.append(tuple(int(x) & 0xFFFFFFFFFFFFFFFF for x in state_t.cpu().tolist()))
+    assert states[1][1] == states[0][1] + 1 and states[2][1] == states[1][1] + 1      # the offset advances on the device
+    assert not torch.equal(outs[0][0], outs[1][0]) and not torch.equal(outs[1][0], outs[2][0])
+    for (o_, dq_, dk_, dv_), (seed, offset) in zip(outs, states):
+        keep = pkg.dropout.keep_mask(seed, offset, B, H, L, S, p)
+        o, dq, dk, dv = _oracle_dropout(q, k, v, do, keep, pkg.dropout.effective_p(p), softmax_n_param=1.0)
+        for got, want, nm in ((o_, o, "out"), (dq_, dq, "dq"), (dk_, dk, "dk"), (dv_, dv, "dv")):
+            _check(got, want, dtype, f"graph replay/{nm}")
 
 
 # ---------------------------------------------------------------- size-independent properties at full BASELINE sizes
