@@ -27,7 +27,7 @@ namespace fasn {
 #ifndef FASN_WS_ATTR
 #define FASN_WS_ATTR
 #endif
-template <typename Tag, int D, int MODE>
+template <typename Tag, int D, int MODE, int GQA = 0>   // GQA = 1: the loop over the query heads of a K/V group is compiled in
 __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(const BwdParams bp) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -60,42 +60,42 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     const int role = wave >> 2;    // 0 = A (S, P, dV), 1 = B (dP, dS, dK)
     const int kbw = wave & 3;      // key block of this wave inside the workgroup's 128 keys
 
-    int bh, kblk;
-    if (VBIAS && p.batch_inner && (p.H & 7) == 0) {
+    // One workgroup per (batch, K/V head, 128-key block). Grouped-query attention (kvg query heads per K/V head): the workgroup
+    // walks the q-tiles of ALL query heads of its group, one head after the other, into the same accumulators - dK / dV come out
+    // per K/V head, summed in fp32 registers, and the K / V fragments are loaded once per group.
+    const int kvg = GQA ? p.kvg : 1;
+    const int Hkv = p.H / kvg;
+    int bhk, kblk;
+    if (VBIAS && p.batch_inner && (Hkv & 7) == 0) {
         // per XCD: (head, key block, batch) with the batch fastest: the B workgroups that read the same bias columns run together
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         const int bb = j % p.B, rest = j / p.B;
         kblk = rest % bp.nblk;
-        bh = bb * p.H + (rest / bp.nblk) * 8 + xcd;
+        bhk = bb * Hkv + (rest / bp.nblk) * 8 + xcd;
     } else {
-        block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
+        block_to_work(blockIdx.x, p.B * Hkv, bp.nblk, bhk, kblk);
     }
     const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
-    const int b = bh / p.H, h = bh % p.H;
+    const int b = bhk / Hkv, hk = bhk % Hkv;
+    int h = hk * kvg;   // current query head (first of the group)
     const int kw0 = kblk * BN + kbw * 32;   // first key of this wave
     const int key = kw0 + l31;
     const int coff = p.Sk - p.Sq;
 
-    const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
-    const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2;
-    const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2;
-    const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2;
-    const float* lsebase = p.lse + (int64_t)bh * p.Sq;
-    const float* dltbase = bp.delta + (int64_t)bh * p.Sq;
+    const char* kbase = p.k + (b * p.ks[0] + hk * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + hk * p.vs[1]) * 2;
+    // per query head (set by head_setup below)
+    const float* lsebase = nullptr;
+    const float* dltbase = nullptr;
+    u32x4 qrw = {0u, 0u, 0u, 0u}, drw = {0u, 0u, 0u, 0u}, brw = {0u, 0u, 0u, 0u};
+    bool kp_keep = true, kp_none = false;
 
-    int ntq = (p.Sq + QT - 1) / QT;
+    const int ntq_all = (p.Sq + QT - 1) / QT;
+    int ntq = ntq_all;
     int tq0 = 0;
     if (causal) {
         const int first_row = kblk * BN - coff;
         tq0 = first_row <= 0 ? 0 : first_row / QT;
-    }
-    // key padding: one flag per lane for the whole kernel. A workgroup none of whose 128 keys is visible (the padded tail of a
-    // batch element) has nothing to accumulate: it walks no q-tile at all and just writes its zeros.
-    bool kp_keep = true, kp_none = false;
-    if (mode_has_keypad(MODE)) {
-        kp_keep = key < p.Sk && (p.mask == nullptr || p.mask[b * p.ms[0] + h * p.ms[1] + key] != 0);   // (no mask: a bias-only call)
-        kp_none = !__any(kp_keep);
-        if (__syncthreads_or(kp_keep ? 1 : 0) == 0) ntq = tq0;
     }
 
     // this wave's operand fragment: K (pre-scaled by c = scale*log2e) for A, V for B  (B operand: col = key, k = 8 features)
@@ -125,7 +125,6 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
         voffQ[i] = (unsigned)(row * (int)p.qs[2] * 2 + ch * 16);
         voffD[i] = (unsigned)(row * (int)bp.dos[2] * 2 + ch * 16);
     }
-    const u32x4 qrw = make_rsrc_words(qbase, bp.qbytes), drw = make_rsrc_words(dobase, bp.dobytes);
     const uint32_t ldsQ_w = lds_addr(ldsQ) + wave * 1024, ldsDO_w = lds_addr(ldsDO) + wave * 1024;
     auto tile_dma = [&](int tq, int buf) {
         const int sq = tq * QT * (int)p.qs[2] * 2, sd = tq * QT * (int)bp.dos[2] * 2;
@@ -163,12 +162,25 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     // additive bias (wave A): block bq = 2*(tile - tq0) + row block lives in slot bq % 3 of the wave's ring as [32 rows][64 B]
     // (32 keys, row-major). One request = 8 x `buffer_load_dword ... lds` (4 rows x 16 dwords each); rows / keys past the end
     // read 0 (range check), so requests past the last block are simply issued like the others and the counts stay uniform.
-    u32x4 brw = {0u, 0u, 0u, 0u};
     unsigned bvo = 0;
-    if (VBIAS) {
-        brw = make_rsrc_words(p.bias + (b * p.bs[0] + h * p.bs[1]) * 2, p.bias_bytes);
-        bvo = (unsigned)(((lane >> 4) * (int)p.bs[2] + kw0 + 2 * (lane & 15)) * 2);
-    }
+    if (VBIAS) bvo = (unsigned)(((lane >> 4) * (int)p.bs[2] + kw0 + 2 * (lane & 15)) * 2);
+    // everything that depends on the query head: Q / dO / bias descriptors, statistics, the key-padding flags (a mask may differ
+    // per head). Key padding: one flag per lane for the whole head; a workgroup none of whose 128 keys is visible (the padded
+    // tail of a batch element) walks no q-tile of that head.
+    auto head_setup = [&]() {
+        const int bh = b * p.H + h;
+        qrw = make_rsrc_words(p.q + (b * p.qs[0] + h * p.qs[1]) * 2, bp.qbytes);
+        drw = make_rsrc_words(bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2, bp.dobytes);
+        lsebase = p.lse + (int64_t)bh * p.Sq;
+        dltbase = bp.delta + (int64_t)bh * p.Sq;
+        if (VBIAS) brw = make_rsrc_words(p.bias + (b * p.bs[0] + h * p.bs[1]) * 2, p.bias_bytes);
+        ntq = ntq_all;
+        if (KPD) {
+            kp_keep = key < p.Sk && (p.mask == nullptr || p.mask[b * p.ms[0] + h * p.ms[1] + key] != 0);   // (no mask: a bias-only call)
+            kp_none = !__any(kp_keep);
+            if (__syncthreads_or(kp_keep ? 1 : 0) == 0) ntq = tq0;
+        }
+    };
     const uint32_t ring_a = lds_addr(ldsBias) + kbw * (3 * 2048);
     auto bias_request = [&](int row0, int slot) {   // 8 vector-memory requests
 #pragma unroll
@@ -178,31 +190,34 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     const char* const ring_rd = ldsBias + kbw * (3 * 2048) + (4 * hi) * 64 + l31 * 2;   // this lane's key, rows 4hi + ...
     using Set0 = std::integral_constant<int, 0>;
 
-    if (tq0 < ntq) {
-        tile_dma(tq0, 0);
-        stats_gload(tq0 * QT);
-        stats_lstore(0);
-        if (VBIAS && role == 0) {
-            bias_request(tq0 * QT, 0);
-            bias_request(tq0 * QT + 32, 1);
-            bias_request(tq0 * QT + 64, 2);
-        }
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 #pragma unroll
     for (int s = 0; s < KS; ++s) retire_loads(opf[s]);
     if (role == 0) {   // K' = K * scale*log2e, rounded to the operand type (like the pre-scaled q of core/flash_attn.py:81-83)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            uint16_t hk[8];
-            __builtin_memcpy(hk, &opf[s], 16);
+            uint16_t hk16[8];
+            __builtin_memcpy(hk16, &opf[s], 16);
             f32x8 f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hk[e]) * p.c;
+            for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hk16[e]) * p.c;
             opf[s] = E::cvt8(f);
         }
     }
+    auto head_prologue = [&]() {   // first q-tile, its statistics and the first three bias blocks of this head
+        if (tq0 < ntq) {
+            tile_dma(tq0, 0);
+            stats_gload(tq0 * QT);
+            stats_lstore(0);
+            if (VBIAS && role == 0) {
+                bias_request(tq0 * QT, 0);
+                bias_request(tq0 * QT + 32, 1);
+                bias_request(tq0 * QT + 64, 2);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
 
     // wave-uniform classification of (q tile tq) x (this wave's 32 keys): identical for the A and the B wave of a key block
     auto classify = [&](int tq, bool& skip, bool& need_mask) {
@@ -408,15 +423,22 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
             if (t + 2 <= ntq) body(t + 2, B2{}, B1{}, B0{});
         }
     };
-    if (tq0 < ntq) {
-        if (role == 0) run(std::integral_constant<int, 0>{});
-        else run(std::integral_constant<int, 1>{});
-    }
+    // (the loop over the group's heads sits INSIDE each role's branch: hoisted per-role addresses stay in their branch)
+    auto all_heads = [&](auto ROLE_) {
+        for (int g = 0; g < kvg; ++g) {
+            h = hk * kvg + g;
+            head_setup();
+            head_prologue();
+            if (tq0 < ntq) run(ROLE_);
+        }
+    };
+    if (role == 0) all_heads(std::integral_constant<int, 0>{});
+    else all_heads(std::integral_constant<int, 1>{});
 
     // ---- epilogue: A writes dV, B writes dK * scale
     if (key < p.Sk) {
-        char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + h * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 2
-                             : bp.dk + (b * bp.dks[0] + h * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
+        char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + hk * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 2     // dK / dV are [B, H / kvg, Sk, D]
+                             : bp.dk + (b * bp.dks[0] + hk * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
         const float sc = role == 0 ? 1.0f : bp.scale;
 #pragma unroll
         for (int d = 0; d < DB; ++d)

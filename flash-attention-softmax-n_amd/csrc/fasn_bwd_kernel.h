@@ -564,7 +564,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 // dK, dV: workgroup = 4 waves x KB x 32 keys, loop over 64-row Q/dO tiles.
 constexpr int QT = 64;  // query rows per tile
 
-template <typename Tag, int D, int KB, int MODE, int OCC, int DROP = 0>
+// GQA = 1 (grouped-query attention, kvg query heads per K/V head): one workgroup per (batch, K/V head, key block) walks the q-tiles
+// of all query heads of its group, one head after the other, into the same fp32 accumulators: dK / dV come out per K/V head.
+template <typename Tag, int D, int KB, int MODE, int OCC, int DROP = 0, int GQA = 0>
 __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams bp) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -588,19 +590,35 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     const int hi = lane >> 5;
     const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
 
-    int bh, kblk;
-    block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
+    const int kvg = GQA ? p.kvg : 1;
+    const int Hkv = p.H / kvg;
+    int bhk, kblk;
+    block_to_work(blockIdx.x, p.B * Hkv, bp.nblk, bhk, kblk);
     const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
-    const int b = bh / p.H, h = bh % p.H;
+    const int b = bhk / Hkv, hk = bhk % Hkv;
     const int kw0 = kblk * BN + wave * (KB * 32);  // first key of this wave
     const int coff = p.Sk - p.Sq;
 
+    f32x16 dkacc[KB][DB], dvacc[KB][DB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[kb][d][r] = 0.f;
+                dvacc[kb][d][r] = 0.f;
+            }
+
+    for (int g = 0; g < kvg; ++g) {   // the query heads of this K/V head (one trip without grouping)
+    const int h = hk * kvg + g, bh = b * p.H + h;
     const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
     const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2;
     const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2;
     const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2;
     const float* lsebase = p.lse + (int64_t)bh * p.Sq;
     const float* dltbase = bp.delta + (int64_t)bh * p.Sq;
+    if (g > 0) __syncthreads();   // the previous head's last tile has been read by every wave before its buffers are refilled
 
     // query tiles that can see this key block: rows i with i + coff >= first key
     int ntq = (p.Sq + QT - 1) / QT;
@@ -638,17 +656,6 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             __builtin_memcpy(&vf[kb][s], &c, 16);
         }
     }
-
-    f32x16 dkacc[KB][DB], dvacc[KB][DB];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dkacc[kb][d][r] = 0.f;
-                dvacc[kb][d][r] = 0.f;
-            }
 
     // Seeded accumulators: K (held in registers, used for S only) is multiplied by c = scale*log2e once; the S accumulator of a
     // query-row block starts at -LSE*log2e and the dP accumulator at -delta of the register's row (the 16 per-row values a lane
@@ -974,8 +981,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         for (int tq = tq0; tq < ntq; ++tq) qtile_body(tq, Buf0{});
     }
 
-    char* dkbase = bp.dk + (b * bp.dks[0] + h * bp.dks[1]) * 2;
-    char* dvbase = bp.dv + (b * bp.dvs[0] + h * bp.dvs[1]) * 2;
+    }   // query heads of the group
+
+    char* dkbase = bp.dk + (b * bp.dks[0] + hk * bp.dks[1]) * 2;   // dK / dV are [B, H / kvg, Sk, D]
+    char* dvbase = bp.dv + (b * bp.dvs[0] + hk * bp.dvs[1]) * 2;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const int key = kw0 + kb * 32 + l31;

@@ -55,9 +55,15 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         if (!(FASN_BWD_VARIANT & 1)) {   // dK, dV: two cooperating waves per key block
             constexpr int smem = 6 * QT * D * 2 + 2 * 16384 + 6 * QT * 4 + (mode_has_vbias(MODE) ? 4 * 3 * 2048 : 0);
             p.nblk = (p.f.Sk + 127) / 128;
-            constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE>;
-            ensure_smem<kern>(smem);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+            if (p.f.kvg > 1) {   // grouped-query attention: one workgroup per K/V head walks the query heads of its group
+                constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE, 1>;
+                ensure_smem<kern>(smem);
+                hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(512), smem, s, p);
+            } else {
+                constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE, 0>;
+                ensure_smem<kern>(smem);
+                hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+            }
             return launch_rc();
         }
     }
@@ -65,9 +71,15 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         constexpr int BN = 4 * KB * 32;
         constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (mode_is_vector(MODE) ? 2 * QT * BN * 2 : 0);
         p.nblk = (p.f.Sk + BN - 1) / BN;
-        constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP>;
-        ensure_smem<kern>(smem);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
+        if (p.f.kvg > 1) {
+            constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 1>;
+            ensure_smem<kern>(smem);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(256), smem, s, p);
+        } else {
+            constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 0>;
+            ensure_smem<kern>(smem);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
+        }
     }
     return launch_rc();
 }

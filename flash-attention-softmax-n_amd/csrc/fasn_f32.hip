@@ -35,7 +35,8 @@ static int bwd_one(BwdParams p, hipStream_t s) {
         p.nblk = (p.f.Sk + 127) / 128;
         constexpr auto kern = &fasn_f32_dkdv_kernel<D, MODE>;
         ensure_smem<kern>(smem);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
+        // one workgroup per K/V head: the kernel sums the query heads of a GQA group itself
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(256), smem, s, p);
     }
     return launch_rc();
 }

@@ -389,12 +389,22 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
     float* const ldsDlt = ldsLse + 2 * 64;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bh, kblk;
-    block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
+    // grouped-query attention: one workgroup per (batch, K/V head, key block) walks all query heads of the group (dK / dV per K/V head)
+    const int kvg = p.kvg, Hkv = p.H / kvg;
+    int bhk, kblk;
+    block_to_work(blockIdx.x, p.B * Hkv, bp.nblk, bhk, kblk);
     constexpr bool GEN = MODE == MODE_GENERAL_SLOW;
     const bool causal = MODE == MODE_CAUSAL || (GEN && p.causal);
-    const int b = bh / p.H, h = bh % p.H;
+    const int b = bhk / Hkv, hk = bhk % Hkv;
     const int kw0 = kblk * BN + wave * 32, key = kw0 + l31, coff = p.Sk - p.Sq;
+    f32x16 dkacc[DB], dvacc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dkacc[d][r] = dvacc[d][r] = 0.f;
+    for (int g = 0; g < kvg; ++g) {
+    const int h = hk * kvg + g, bh = b * p.H + h;
+    if (g > 0) __syncthreads();
     GenElem ge;
     if (GEN) ge.init(p, b, h);
     const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 4;
@@ -417,11 +427,6 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
             vf[c] = *reinterpret_cast<const f32x4*>(p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1] + (int64_t)key * p.vs[2]) * 4 + (2 * c + hi) * 16);
         }
     }
-    f32x16 dkacc[DB], dvacc[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dkacc[d][r] = dvacc[d][r] = 0.f;
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qbase), 0, bp.qbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dobase), 0, bp.dobytes, 0x00020000);
     St sQ, sD;
@@ -519,9 +524,10 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
         stats_lstore(buf ^ 1);
         __syncthreads();
     }
-    if (ok) {
-        char* rk = bp.dk + (b * bp.dks[0] + h * bp.dks[1] + (int64_t)key * bp.dks[2]) * 4;
-        char* rv = bp.dv + (b * bp.dvs[0] + h * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 4;
+    }   // query heads of the group
+    if (key < p.Sk) {
+        char* rk = bp.dk + (b * bp.dks[0] + hk * bp.dks[1] + (int64_t)key * bp.dks[2]) * 4;   // dK / dV are [B, H / kvg, Sk, D]
+        char* rv = bp.dv + (b * bp.dvs[0] + hk * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 4;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll

@@ -139,8 +139,9 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         S = k.shape[2]
         # K/V with a broadcast (stride-0) head dimension get per-head gradients that are summed below
         dq = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
-        dk = torch.empty((B, H, S, D), dtype=q.dtype, device=q.device)
-        dv = torch.empty((B, H, S, v.shape[3]), dtype=q.dtype, device=q.device)
+        Hkv = k.shape[1]   # grouped-query attention: each dK/dV workgroup sums the query heads of its K/V head in registers
+        dk = torch.empty((B, Hkv, S, D), dtype=q.dtype, device=q.device)
+        dv = torch.empty((B, Hkv, S, v.shape[3]), dtype=q.dtype, device=q.device)
         delta = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
         a = BwdArgs()
         _fill_fwd(a.fwd, q, k, v, o, lse, mask, bias, ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, 0, 0, ctx.rng)
@@ -158,10 +159,6 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
             _lib.check(lib.fasn_bwd(a, _stream_ptr(q.device)), "fasn_bwd")
         if dbias is not None and dbias.dtype != bias.dtype:
             dbias = dbias.to(bias.dtype)
-        Hkv = k.shape[1]
-        if Hkv != H:   # grouped-query attention: the kernels write per-query-head gradients, each K/V head gets its group's sum
-            dk = dk.view(B, Hkv, H // Hkv, S, D).sum(2, dtype=torch.float32).to(dk.dtype)
-            dv = dv.view(B, Hkv, H // Hkv, S, dv.shape[3]).sum(2, dtype=torch.float32).to(dv.dtype)
         return dq, dk, dv, None, dbias, None, None, None, None, None
 
 

@@ -88,7 +88,8 @@ typedef struct fasn_fwd_args {
                               pass the SAME values to fasn_bwd (see flash-attention-softmax-n_amd/dropout.py) */
     int32_t kv_group;      /* grouped-query attention (ABI 2): query head h reads K/V head h / kv_group, i.e. k and v are
                               [B, H / kv_group, Sk, D] addressed through their head stride; 0 or 1 = one K/V head per query
-                              head. fasn_bwd still writes dk / dv per QUERY head [B,H,Sk,D]; the caller sums each group. */
+                              head. fasn_bwd writes dk / dv per K/V head, [B, H / kv_group, Sk, D]: each dK/dV workgroup walks the
+                              query heads of its group and accumulates their contributions in registers (fp32). */
     const uint64_t* rng_state; /* optional (ABI 3): DEVICE pointer to {seed, offset} (8-byte aligned). When set, the kernels read the
                               dropout stream position from device memory instead of `seed` / `offset` above, so a captured HIP graph
                               that also captures fasn_rng_advance() draws a fresh mask on every replay. Pass the same pointer (and the
@@ -105,8 +106,8 @@ typedef struct fasn_bwd_args {
     fasn_fwd_args fwd; /* same views as forward; o and lse are inputs here */
     fasn_view4 dout;   /* [B,H,Sq,Dv] */
     fasn_view4 dq;     /* [B,H,Sq,D]  out */
-    fasn_view4 dk;     /* [B,H,Sk,D]  out */
-    fasn_view4 dv;     /* [B,H,Sk,Dv] out */
+    fasn_view4 dk;     /* [B,H/kv_group,Sk,D]  out (summed over the query heads of a GQA group inside the kernel) */
+    fasn_view4 dv;     /* [B,H/kv_group,Sk,Dv] out */
     float* delta;      /* [B,H,Sq] fp32 scratch */
     void* workspace;
     size_t workspace_bytes;

@@ -15,8 +15,8 @@ import flash_attention_softmax_n_amd.synth as synth
 
 pytestmark = pytest.mark.gpu
 
-REF_ATOL = {torch.float16: 1e-2, torch.bfloat16: 5e-2}   # reference GPU test tolerances (rtol 0)
-REL_TRUE = {torch.float16: 2.0 ** -9, torch.bfloat16: 2.0 ** -6}  # vs fp32 oracle, relative to the tensor's max |x|
+REF_ATOL = {torch.float16: 1e-2, torch.bfloat16: 5e-2, torch.float32: 1e-3}   # reference GPU test tolerances (rtol 0)
+REL_TRUE = {torch.float16: 2.0 ** -9, torch.bfloat16: 2.0 ** -6, torch.float32: 2e-5}  # vs fp32 oracle, relative to the tensor's max |x|
 
 
 def _rand(shape, dtype, dev, seed, std=0.5):
@@ -900,13 +900,33 @@ def test_fp16_large_scale_does_not_overflow_the_prescaled_operand(pkg, dev, caus
     assert (out.float().cpu() - want).abs().max().item() <= 1e-2
 
 
+def test_grouped_query_attention_with_dropout(pkg, dev):
+    """the dropout stream is indexed by QUERY head, the dK/dV sum runs over the group inside the kernel"""
+    dtype, D, p = torch.bfloat16, 64, 0.2
+    B, H, Hkv, L, S = 2, 8, 2, 200, 264
+    G = H // Hkv
+    q = _rand((B, H, L, D), dtype, dev, 1).requires_grad_()
+    k, v = (_rand((B, Hkv, S, D), dtype, dev, s).requires_grad_() for s in (2, 3))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    torch.manual_seed(99)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, dropout_p=p, is_causal=True)
+    seed, offset = pkg.flash_attn.last_dropout_state()
+    out.backward(do)
+    keep = pkg.dropout.keep_mask(seed, offset, B, H, L, S, p)
+    o, dq, dk, dv = _oracle_dropout(q, k.repeat_interleave(G, dim=1), v.repeat_interleave(G, dim=1), do, keep, pkg.dropout.effective_p(p),
+                                    softmax_n_param=1.0, is_causal=True)
+    dk, dv = (t.view(B, Hkv, G, S, D).sum(2) for t in (dk, dv))
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"gqa dropout {nm}")
+
+
 # ---------------------------------------------------------------- grouped-query attention (fewer K/V heads than query heads)
-@pytest.mark.parametrize("D", [64, 128])
-@pytest.mark.parametrize("kind", ["plain", "causal+keypad", "bias", "decode"])
-def test_grouped_query_attention(pkg, dev, kind, D):
+@pytest.mark.parametrize("D,dtype", [(32, torch.bfloat16), (64, torch.bfloat16), (128, torch.bfloat16), (128, torch.float16),
+                                     (64, torch.float32)])
+@pytest.mark.parametrize("kind", ["plain", "causal+keypad", "bias", "bias+keypad", "dense-mask", "decode"])
+def test_grouped_query_attention(pkg, dev, kind, D, dtype):
     """K/V with H/G heads: query head h reads K/V head h // G through the head stride (generalises the reference's 3-D shared
     K/V, flash_attn.py:75-79); the oracle sees the K/V heads repeated; dK/dV are the sums over each group"""
-    dtype = torch.bfloat16
     B, H, Hkv = 2, 8, 2
     L, S = (1, 4096) if kind == "decode" else (200, 264)
     q = _rand((B, H, L, D), dtype, dev, 1).requires_grad_()
@@ -915,9 +935,12 @@ def test_grouped_query_attention(pkg, dev, kind, D):
     do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
     mask = bias = None
     causal = kind == "causal+keypad"
-    if causal:
+    if causal or kind == "bias+keypad":
         mask = synth.keypad_mask(B, S, device=dev)
-    if kind == "bias":
+    if kind == "dense-mask":   # per-(head,row) boolean mask: the element-load path of every kernel
+        mask = (torch.rand(B, H, L, S, generator=torch.Generator().manual_seed(5)) < 0.8).to(dev)
+        mask[..., 0] = True
+    if kind.startswith("bias"):
         bias = torch.randn(H, L, S, generator=torch.Generator().manual_seed(2)).to(dtype).to(dev)
     out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, is_causal=causal, attn_mask=mask, attn_bias=bias)
     out.backward(do)
