@@ -190,7 +190,26 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     const char* const ring_rd = ldsBias + kbw * (3 * 2048) + (4 * hi) * 64 + l31 * 2;   // this lane's key, rows 4hi + ...
     using Set0 = std::integral_constant<int, 0>;
 
+    auto head_issue = [&]() {   // first q-tile, its statistics and the first three bias blocks of this head
+        if (tq0 < ntq) {
+            tile_dma(tq0, 0);
+            stats_gload(tq0 * QT);
+            stats_lstore(0);
+            if (VBIAS && role == 0) {
+                bias_request(tq0 * QT, 0);
+                bias_request(tq0 * QT + 32, 1);
+                bias_request(tq0 * QT + 64, 2);
+            }
+        }
+    };
+    // one query head per K/V head (GQA = 0): the head's setup and first requests are issued here, in front of the wait for the
+    // K / V fragments, outside the role branches (the per-head state then is loop-invariant for both roles)
+    if (!GQA) {
+        head_setup();
+        head_issue();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!GQA) __syncthreads();
 #pragma unroll
     for (int s = 0; s < KS; ++s) retire_loads(opf[s]);
     if (role == 0) {   // K' = K * scale*log2e, rounded to the operand type (like the pre-scaled q of core/flash_attn.py:81-83)
@@ -204,17 +223,8 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
             opf[s] = E::cvt8(f);
         }
     }
-    auto head_prologue = [&]() {   // first q-tile, its statistics and the first three bias blocks of this head
-        if (tq0 < ntq) {
-            tile_dma(tq0, 0);
-            stats_gload(tq0 * QT);
-            stats_lstore(0);
-            if (VBIAS && role == 0) {
-                bias_request(tq0 * QT, 0);
-                bias_request(tq0 * QT + 32, 1);
-                bias_request(tq0 * QT + 64, 2);
-            }
-        }
+    auto head_prologue = [&]() {   // (grouped-query walk: per head)
+        head_issue();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
@@ -432,8 +442,13 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
             if (tq0 < ntq) run(ROLE_);
         }
     };
-    if (role == 0) all_heads(std::integral_constant<int, 0>{});
-    else all_heads(std::integral_constant<int, 1>{});
+    if (GQA) {
+        if (role == 0) all_heads(std::integral_constant<int, 0>{});
+        else all_heads(std::integral_constant<int, 1>{});
+    } else if (tq0 < ntq) {
+        if (role == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+    }
 
     // ---- epilogue: A writes dV, B writes dK * scale
     if (key < p.Sk) {

@@ -19,8 +19,14 @@ def q(db, sql):
         return []
 
 
+only = sys.argv[3] if len(sys.argv) > 3 else None   # "w_p": summarise ONE pass directory into OUTDIR/frag_w_p.json (raw .db files can then go)
+if only is None and glob.glob(os.path.join(root, "frag_*.json")):
+    for fr in sorted(glob.glob(os.path.join(root, "frag_*.json"))):
+        out.update(json.load(open(fr)))
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 for d in sorted(glob.glob(os.path.join(root, "*_*"))):
-    if not os.path.isdir(d):
+    if not os.path.isdir(d) or (only and os.path.basename(d) != only):
         continue
     w, p = os.path.basename(d).split("_")
     want = (lambda n: "fasn_fwd" in n) if p == "fwd" else (lambda n: "fasn_bwd" in n)
@@ -46,4 +52,6 @@ for d in sorted(glob.glob(os.path.join(root, "*_*"))):
         if c in ctr:
             ent[c] = ctr[c]
     out[f"{w}:{p}"] = ent
+    if only:
+        json.dump({f"{w}:{p}": ent}, open(os.path.join(root, f"frag_{only}.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
