@@ -14,16 +14,20 @@
 // published by the barrier that ends A's iteration t anyway: one barrier per q-tile, no extra synchronisation. Q / dO tiles
 // live in three LDS buffers (tile t for A, t-1 for B, t+1 in flight), P in two.
 // Mask / bias work exists in wave A only (B just receives zeros for hidden scores). The additive bias of a block ([32 rows] x
-// the wave's [32 keys], 2 KiB) goes HBM -> LDS by `buffer_load_dword ... lds` into a WAVE-PRIVATE ring of three slots, three
+// the wave's [32 keys], 2 KiB) goes HBM -> LDS by two `buffer_load_dwordx4 ... lds` into a WAVE-PRIVATE ring of three slots, three
 // blocks (one and a half q-tiles) ahead: private, so no barrier is involved - the wave re-requests a slot right after reading
 // it - and no register is written asynchronously (the waits are hand-counted vmcnt next to the Q / dO requests). A lane owns a
-// key column, so it reads its 16 rows of a block with 16 two-byte LDS reads. A key-padding mask is one flag per lane.
+// key column, so it reads its 16 rows of a block with four transposing LDS reads (`ds_read_b64_tr_b16`). A key-padding mask is
+// one flag per lane, applied to the packed weights.
 // Dense boolean masks (MODE_GENERAL) stay on the one-wave kernel.
 #pragma once
 #include "fasn_bwd_kernel.h"
 
 namespace fasn {
 
+#ifndef FASN_EXP_BIASHOT
+#define FASN_EXP_BIASHOT 0   // experiment: every bias request reads the first rows (always an L2 hit): separates fetch latency from issue cost
+#endif
 #ifndef FASN_WS_ATTR
 #define FASN_WS_ATTR
 #endif
@@ -160,10 +164,11 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     };
 
     // additive bias (wave A): block bq = 2*(tile - tq0) + row block lives in slot bq % 3 of the wave's ring as [32 rows][64 B]
-    // (32 keys, row-major). One request = 8 x `buffer_load_dword ... lds` (4 rows x 16 dwords each); rows / keys past the end
+    // (32 keys, row-major). One request = 2 x `buffer_load_dwordx4 ... lds` (16 rows x 64 bytes each; one such instruction costs about as much issue time as a dword one); rows / keys past the end
     // read 0 (range check), so requests past the last block are simply issued like the others and the counts stay uniform.
+    constexpr int kBiasPieces = 2;   // vector-memory requests per block: 2 x (16 rows x 64 bytes)
     unsigned bvo = 0;
-    if (VBIAS) bvo = (unsigned)(((lane >> 4) * (int)p.bs[2] + kw0 + 2 * (lane & 15)) * 2);
+    if (VBIAS) bvo = (unsigned)(((lane >> 2) * (int)p.bs[2] + kw0 + 8 * (lane & 3)) * 2);   // 4 lanes x 16 bytes cover one row's 32 keys
     // everything that depends on the query head: Q / dO / bias descriptors, statistics, the key-padding flags (a mask may differ
     // per head). Key padding: one flag per lane for the whole head; a workgroup none of whose 128 keys is visible (the padded
     // tail of a batch element) walks no q-tile of that head.
@@ -182,12 +187,24 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
         }
     };
     const uint32_t ring_a = lds_addr(ldsBias) + kbw * (3 * 2048);
-    auto bias_request = [&](int row0, int slot) {   // 8 vector-memory requests
+    auto bias_request = [&](int row0, int slot) {   // kBiasPieces vector-memory requests
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            lds_dma4(brw, __builtin_amdgcn_readfirstlane(ring_a + slot * 2048 + i * 256), bvo, (row0 + 4 * i) * (int)p.bs[2] * 2);
+        for (int i = 0; i < kBiasPieces; ++i)
+            lds_dma16(brw, __builtin_amdgcn_readfirstlane(ring_a + slot * 2048 + i * 1024), bvo, (FASN_EXP_BIASHOT ? 16 * i : row0 + 16 * i) * (int)p.bs[2] * 2);
     };
-    const char* const ring_rd = ldsBias + kbw * (3 * 2048) + (4 * hi) * 64 + l31 * 2;   // this lane's key, rows 4hi + ...
+    // A lane owns a key column: its 16 rows of a block come out of the row-major ring through four transposing reads (lane i of a
+    // 16-lane group addresses row 4hi + i/4, keys 4(i%4).. of its half and receives rows 4hi + {0..3} of key i), as packed pairs.
+    const char* const ring_rd = ldsBias + kbw * (3 * 2048) + (4 * hi + ((lane & 15) >> 2)) * 64 + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+    // (Measured and rejected: wave B touching the rows of a later tile as an L2 prefetch - one dword per row is 64 cache lines per
+    // request and costs the texture addresser more than the hidden latency is worth: C4 backward 15.5 -> 16.8 ms. With every bias
+    // request forced to hit L2 (FASN_EXP_BIASHOT) the same launch takes 14.7 ms: that is all the fetch latency is worth.)
+    auto bias_read = [&](int slot, u32x2 (&br)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, ring_rd + slot * 2048 + g * 512));
+            __builtin_memcpy(&br[g], &t, 8);
+        }
+    };
     using Set0 = std::integral_constant<int, 0>;
 
     auto head_issue = [&]() {   // first q-tile, its statistics and the first three bias blocks of this head
@@ -254,18 +271,20 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
         const bool more = tq + 1 < ntq;
         bool skip, need_mask;
         classify(tq, skip, need_mask);
-        // start value of the S accumulator: -lse*log2e of the register's row (+ bias*log2e; -inf where the lane's key is padded)
-        auto start = [&](int qb, int slot, f32x16& sacc) {
+        // start value of the S accumulator: -lse*log2e of the register's row (+ bias*log2e). A padded key is hidden after the
+        // exponential (its packed weights are cleared), not here.
+        auto start = [&](int qb, const u32x2 (&br)[4], f32x16& sacc) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 a = *LDS_PTR(const f32x4, tL + qb * 32 + 8 * g + 4 * hi);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
                     float v = a[e];
-                    if (VBIAS) v = __builtin_fmaf(E::to_f32(*LDS_PTR(const uint16_t, ring_rd + slot * 2048 + ((r & 3) + 8 * (r >> 2)) * 64)), kLog2e, v);
-                    if (KPD) v = kp_keep ? v : -INFINITY;
-                    sacc[r] = v;
+                    if (VBIAS) {
+                        const uint32_t w = br[g][e >> 1];
+                        v = __builtin_fmaf(E::to_f32((uint16_t)((e & 1) ? (w >> 16) : (w & 0xffffu))), kLog2e, v);
+                    }
+                    sacc[4 * g + e] = v;
                 }
             }
         };
@@ -297,6 +316,16 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
             u32x4 w0, w1;
             __builtin_memcpy(&w0, &pfr[0], 16);
             __builtin_memcpy(&w1, &pfr[1], 16);
+            if (KPD) {   // key padding: the lane's key is hidden for every row - clear its packed weights (also what dV multiplies)
+                const uint32_t kpm = kp_keep ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    w0[e] &= kpm;
+                    w1[e] &= kpm;
+                }
+                __builtin_memcpy(&pfr[0], &w0, 16);
+                __builtin_memcpy(&pfr[1], &w1, 16);
+            }
             *LDS_PTR(u32x4, ps) = w0;
             *LDS_PTR(u32x4, ps + 1024) = w1;
         };
@@ -309,8 +338,8 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
                     acc[d] = E::mfma(dot, pfr[t2], acc[d]);
                 }
         };
-        // Request order of this wave per tile: [bias block bq+3 (8)] [next Q / dO tile (2*NLD)] [bias block bq+4 (8)]; the wait that
-        // ends an iteration leaves only the last 8 in flight, so both blocks read here landed at least one barrier ago. A slot
+        // Request order of this wave per tile: [bias block bq+3 (2)] [next Q / dO tile (2*NLD)] [bias block bq+4 (2)]; the wait that
+        // ends an iteration leaves only the last 2 in flight, so both blocks read here landed at least one barrier ago. A slot
         // is re-requested right after its reads were issued (the data of a request arrives hundreds of cycles after the reads
         // have left the LDS queue).
         constexpr int slot0 = (2 * buf) % 3, slot1 = (2 * buf + 1) % 3;   // buf = (tq - tq0) % 3
@@ -322,11 +351,15 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
             else soft(qb, sacc, pfr, std::false_type{});
             dv_gemm(qb, pfr);
         };
-        start(0, slot0, sacc);
+        // (reading a block's bias one block / one barrier early measured slower: 8 more live registers spill)
+        u32x2 b0[4] = {}, b1[4] = {};
+        if (VBIAS) bias_read(slot0, b0);
+        start(0, b0, sacc);
         if (VBIAS) bias_request(r0 + QT + 32, slot0);   // block bq + 3 = second block of the next tile
         if (more) tile_dma(tq + 1, decltype(BN_)::value);
         if (!skip) block(0);
-        start(1, slot1, sacc);
+        if (VBIAS) bias_read(slot1, b1);
+        start(1, b1, sacc);
         if (VBIAS) bias_request(r0 + 2 * QT, slot1);    // block bq + 4 = first block of the tile after the next
         if (!skip) block(1);
     };
@@ -422,8 +455,8 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
 #endif
             }
             if (ROLE == 1 && t + 1 < ntq) stats_lstore(decltype(BN_)::value);
-            // tile t+1 has landed. Wave A in the bias modes leaves its newest bias request (8 pieces, issued after the tile's) in flight
-            if (VBIAS && ROLE == 0 && t < ntq) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // tile t+1 has landed. Wave A in the bias modes leaves its newest bias request (2 pieces, issued after the tile's) in flight
+            if (VBIAS && ROLE == 0 && t < ntq) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kBiasPieces) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         };
