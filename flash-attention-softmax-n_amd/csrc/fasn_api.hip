@@ -129,10 +129,11 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
         const bool vec = (!a->bias.ptr || p.bias_vec) && (!a->mask.ptr || p.mask_vec);
         l.mode = !vec ? MODE_GENERAL_SLOW : (a->bias.ptr && a->mask.ptr) ? MODE_GENERAL : a->bias.ptr ? MODE_GENERAL_B : MODE_GENERAL_M;
         // key-padding mask (one byte per key for the whole (b,h), no bias): plain kernels + a per-tile visibility word
-        if (a->mask.ptr && !a->bias.ptr && a->mask.stride[2] == 0 && a->mask.stride[3] == 1) {
+        const bool kp_fits = (a->Sk + KT - 1) / KT <= kFwdKpMaxTiles;   // the forward kernels keep one visibility word per tile in LDS
+        if (a->mask.ptr && !a->bias.ptr && a->mask.stride[2] == 0 && a->mask.stride[3] == 1 && kp_fits) {
             p.keypad_fallback = l.mode;   // what split-K and the fp32 kernels use: they have no key-padding path of their own
             l.mode = MODE_KEYPAD;
-        } else if (a->mask.ptr && a->bias.ptr && p.bias_vec && a->mask.stride[2] == 0 && a->mask.stride[3] == 1 && a->dtype != FASN_DTYPE_F32) {
+        } else if (a->mask.ptr && a->bias.ptr && p.bias_vec && a->mask.stride[2] == 0 && a->mask.stride[3] == 1 && a->dtype != FASN_DTYPE_F32 && kp_fits) {
             // vector bias + key-padding mask (ALiBi on a padded batch): bias through the vector path, mask as visibility bits
             p.keypad_fallback = l.mode;   // dropout and split-K instantiations take the dense-mask general mode instead
             l.mode = MODE_BIAS_KEYPAD;

@@ -148,15 +148,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
             bias_request(1, 1);
         }
     }
-    if (KP) {   // visibility word of every 64-key tile: one ballot per tile, 8 waves in turn
-        const uint8_t* mrow = p.mask ? p.mask + (b * p.ms[0] + h * p.ms[1]) : nullptr;
-        for (int t = wave; t < ntiles; t += 8) {
-            const int key = t * KT + lane;
-            const bool vis = key < p.Sk && (mrow == nullptr || mrow[key] != 0);
-            const uint64_t w = __ballot(vis);
-            if (lane == 0) ldsKP[t] = w;
-        }
-    }
+    if (KP) kp_build_words(ldsKP, p.mask ? p.mask + (b * p.ms[0] + h * p.ms[1]) : nullptr, p.Sk, ntiles, tid, 512);   // visibility word of every 64-key tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
@@ -239,24 +231,36 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
         vec8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            // S' = seed (+ bias) + K Q'^T. The MFMA chain is instantiated per start-value variant, so that the common one takes the
+            // seed tuple itself as the C operand of its first MFMA (no copy): a boundary tile of a key-padding mask (wave-uniform,
+            // at most one per workgroup) and the bias modes build their start values per element.
+            auto s_gemm = [&](f32x16 c0) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
+                    c0 = E::mfma(kf, opf[s], c0);
+                }
+                return c0;
+            };
             f32x16 sacc;
+            if (VBIAS || (KP && kp_bits != ~0ull)) {
+                f32x16 c0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = seed[r];
-                if (VBIAS) {
-                    const uint32_t w = braw[kb][r >> 2][(r & 3) >> 1];
-                    v = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), kLog2e, stat);
+                for (int r = 0; r < 16; ++r) {
+                    float v = seed[r];
+                    if (VBIAS) {
+                        const uint32_t w = braw[kb][r >> 2][(r & 3) >> 1];
+                        v = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), kLog2e, stat);
+                    }
+                    if (KP) {
+                        const int bit = kb * 32 + (KPERM ? 16 * hi + r : (r & 3) + 8 * (r >> 2) + 4 * hi);
+                        if (kp_bits != ~0ull) v = ((kp_bits >> bit) & 1ull) ? v : -INFINITY;   // (wave-uniform test: all-visible tiles skip the selects)
+                    }
+                    c0[r] = v;
                 }
-                if (KP) {
-                    const int bit = kb * 32 + (KPERM ? 16 * hi + r : (r & 3) + 8 * (r >> 2) + 4 * hi);
-                    if (kp_bits != ~0ull) v = ((kp_bits >> bit) & 1ull) ? v : -INFINITY;   // (wave-uniform test: all-visible tiles skip the selects)
-                }
-                sacc[r] = v;
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
-                sacc = E::mfma(kf, opf[s], sacc);
+                sacc = s_gemm(c0);
+            } else {
+                sacc = s_gemm(seed);
             }
             auto elems = [&](auto MASKED) {
 #pragma unroll

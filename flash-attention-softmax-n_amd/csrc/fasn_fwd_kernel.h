@@ -83,8 +83,41 @@ struct FwdParams {
 };
 
 constexpr int KT = 64;  // keys per tile
+// key-padding modes: visibility words (one per K/V tile) kept in LDS by the forward kernels: 4 KiB, Sk <= 32768. Longer key
+// sequences take the dense-mask general mode of the same mask (fasn_api.hip).
+constexpr int kFwdKpMaxTiles = 512;
 // fast-path guard: a lane's partial row sum over one tile (32 values) must stay <= 2^8; any single p > 2^8 trips it
 constexpr float kSumLimit = 256.0f;
+
+// Visibility words of a key-padding mask row: words[t] bit j = key 64t + j is visible (mask byte != 0 and key < Sk), for tiles
+// [0, ntiles). Thread `tid` of `nthreads` turns 16 mask bytes into 16 bits per step (one 16-byte load; a row that is not dword
+// aligned takes byte loads) and stores them as one uint16 - the caller's barrier publishes the words. mrow == nullptr: no mask.
+FASN_DEV void kp_build_words(uint64_t* words, const uint8_t* mrow, int Sk, int ntiles, int tid, int nthreads) {
+    uint16_t* const bits16 = reinterpret_cast<uint16_t*>(words);
+    const bool aligned = (reinterpret_cast<uintptr_t>(mrow) & 3) == 0;
+    const __amdgpu_buffer_rsrc_t mrs16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(mrow), 0, (mrow && aligned) ? (unsigned)((Sk + 3) & ~3) : 0u, 0x00020000);   // whole dwords: the range check works per dword
+    for (int c = tid; c * 16 < ntiles * 64; c += nthreads) {
+        uint32_t bits = 0;
+        if (mrow == nullptr) {
+            bits = 0xffffu;
+        } else if (aligned) {
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(mrs16, c * 16, 0, 0);   // bytes past the last dword read as 0
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // byte != 0 -> bit: OR-fold each byte into its bit 0, then gather the four flags by a multiply
+                uint32_t t = w[e] | (w[e] >> 4);
+                t |= t >> 2;
+                t |= t >> 1;
+                bits |= (((t & 0x01010101u) * 0x01020408u) >> 24 & 0xfu) << (4 * e);
+            }
+        } else {
+            for (int e = 0; e < 16; ++e)
+                if (c * 16 + e < Sk && mrow[c * 16 + e] != 0) bits |= 1u << e;
+        }
+        const int left = Sk - c * 16;   // keys past Sk are hidden (also the bytes of the last dword behind Sk)
+        if (left < 16) bits = left <= 0 ? 0u : (bits & ((1u << left) - 1u));
+        bits16[c] = (uint16_t)bits;
+    }
+}
 
 // ABL (developer ablation, never dispatched by the ABI): 1 = no exponentials (P := raw S), 2 = no QK^T MFMAs,
 // 3 = no PV MFMAs, 4 = neither MFMA group, 5 = no K/V LDS fragment reads, 6 = no staging and no barrier,
@@ -172,26 +205,19 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         const int nt_c = kmax < 0 ? 0 : (kmax / KT + 1);
         ntiles = min(ntiles, nt_c);
     }
-    if (KP && p.mask != nullptr) {
-        // key-padding mask: trailing tiles without a visible key are not walked at all (no staging, no barrier). The workgroup
-        // scans the mask bytes of its key range once, 16 per thread and step (needs a dword-aligned mask row; else no trimming).
-        int* const s_last = reinterpret_cast<int*>(smem + 2 * (RING == 2 ? 3 : 2) * (KT * D * 2) + (mode_is_vector(MODE) ? NW * QB * 6144 : 0));   // 16 spare bytes behind the tiles / images
-        const uint8_t* mrow = p.mask + (b * p.ms[0] + h * p.ms[1]);
-        if ((reinterpret_cast<uintptr_t>(mrow) & 3) == 0) {
-            if (tid == 0) *s_last = -1;
-            __syncthreads();
-            const __amdgpu_buffer_rsrc_t mrs16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(mrow), 0, (unsigned)((p.Sk + 3) & ~3), 0x00020000);   // whole dwords: the range check works per dword; bytes past Sk in the last one can only keep a tile
-            int mylast = -1;
-            for (int c = tid; c * 16 < ntiles * KT; c += NT) {
-                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(mrs16, c * 16, 0, 0);   // bytes past Sk read as 0
-                if ((w[0] | w[1] | w[2] | w[3]) != 0u) mylast = c >> 2;
-            }
+    // Key-padding mask: the workgroup turns the mask bytes of its key range into one visibility word per K/V tile, ONCE, in LDS
+    // (thread c: 16 bytes -> 16 bits; a tile then costs one uniform ds_read_b64 instead of a global load per wave and tile, whose
+    // compiler-counted wait also drained the K/V prefetch). Trailing tiles without a visible key are not walked at all.
+    uint64_t* const ldsKP = reinterpret_cast<uint64_t*>(smem + 2 * (RING == 2 ? 3 : 2) * (KT * D * 2) + (mode_is_vector(MODE) ? NW * QB * 6144 : 0));   // [kFwdKpMaxTiles]
+    if (KP) {
+        kp_build_words(ldsKP, p.mask == nullptr ? nullptr : p.mask + (b * p.ms[0] + h * p.ms[1]), p.Sk, ntiles, tid, NT);
+        __syncthreads();
+        int last = -1;
+        for (int t = lane; t < ntiles; t += 64)
+            if (ldsKP[t] != 0ull) last = t;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mylast = max(mylast, __shfl_xor(mylast, o));
-            if (lane == 0 && mylast >= 0) atomicMax(s_last, mylast);
-            __syncthreads();
-            ntiles = min(ntiles, *s_last + 1);
-        }
+        for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
+        ntiles = min(ntiles, __builtin_amdgcn_readfirstlane(last) + 1);
     }
     const int t_begin = SPLIT ? split * p.tps : 0;   // tps is a multiple of 6: t & 1 and t % 3 select the LDS buffer as if t started at 0
     if (SPLIT) ntiles = min(ntiles, t_begin + p.tps);
@@ -400,12 +426,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int wave_first_vis = qw0 + coff;                 // last visible key of the wave's first row
     const int wave_last_vis = qw0 + QB * 32 - 1 + coff;    // last visible key of the wave's last row
 
-    __amdgpu_buffer_rsrc_t kprs;
-    uint32_t kp_next = 0;
-    if (KP) {
-        kprs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.mask + (b * p.ms[0] + h * p.ms[1])), 0, (unsigned)p.Sk, 0x00020000);
-        kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, t_begin * KT, 0);   // keys past Sk read as hidden
-    }
+    // this tile's visibility word is read (uniform address) while the tile before is computed
+    uint64_t kp_next = 0;
+    if (KP && t_begin < ntiles) kp_next = ldsKP[t_begin];
 
     // Direct-to-LDS vector kernels (LATE): the image of a tile is moved LDS -> registers at the END of the tile before, between
     // the wait that precedes the barrier and the barrier itself, and the image after it is requested there: the LDS latency
@@ -454,10 +477,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         else if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
 
         uint64_t kp_bits = ~0ull;
-        if (KP) {   // this tile's visibility word; the next tile's bytes go in flight (older than the K/V prefetch in the vmcnt queue;
-                    // vector modes: requested after the image wait below, so the counted vmcnt there sees the same queue as without it)
-            kp_bits = __ballot(kp_next != 0);
-            if (!VEC) kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
+        if (KP) {   // (the builtin returns a signed int)
+            kp_bits = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kp_next >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)kp_next);
+            kp_next = ldsKP[min(t + 1, ntiles - 1)];
         }
         // wave-uniform tile classification
         bool skip = false;       // no visible element for this wave
@@ -477,7 +499,6 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         u32x2 braw[QB][2][4];
         if (SLOW) need_mask = true;
         if (LATE) {   // the image is already in registers (end of the previous tile); only the requests of this tile remain
-            if (KP) kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
             stage_direct(t + 2, buf2);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
@@ -493,7 +514,6 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             image_to_regs(mraw, braw);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before the next one is requested
-            if (KP) kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0);
             gen_dma(t + 1);                                        // past-the-end tiles are out of range: zeros
             stage_load(t + 1 + RING, LSET);
         }
@@ -503,6 +523,28 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 
             // ---- S^T = K Q^T : acc[qb][kb], 32 keys x 32 queries each
             f32x16 sacc[QB][2];
+            // (instantiated once per start-value variant below: the common variant then feeds the -m tuple itself to the first MFMA
+            // of every key block as an untied C operand instead of merging with the boundary-tile variant through copies)
+            auto qk_gemm = [&]() {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        vec8 kf;
+                        if (ABL == 5 || ABL == 7) { kf = qf[0][s]; asm volatile("" : "+v"(kf)); }
+                        else kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) {
+                            if (ABL == 2 || ABL == 4) {
+                                asm volatile("" : "+v"(kf));
+                                sacc[qb][kb][s] += 1.0f;
+                            } else {
+                                sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
+                            }
+                        }
+                    }
+                }
+            };
             if (VEC) {
                 // S' starts from the additive term: bias*log2e/c where the mask byte is set, -inf where it is clear
                 // (S' = add + q.k, y = c*S'): from here on the tile is handled exactly like a plain one
@@ -532,6 +574,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             for (int qb = 0; qb < QB; ++qb) sacc[qb][kb][r] = ((w >> r) & 1u) ? sacc[qb][kb][r] : -INFINITY;
                     }
                 }
+                qk_gemm();
             } else if (KP && kp_bits != ~0ull) {   // boundary tile of a key-padding mask: hidden keys start at -inf
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
@@ -543,6 +586,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                         for (int qb = 0; qb < QB; ++qb) sacc[qb][kb][r] = vis_r ? (SEED ? mseed[qb][r] : 0.f) : -INFINITY;
                     }
                 }
+                qk_gemm();
             } else {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
@@ -550,26 +594,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = SEED ? mseed[qb][r] : 0.f;
+                qk_gemm();
             }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    vec8 kf;
-                    if (ABL == 5 || ABL == 7) { kf = qf[0][s]; asm volatile("" : "+v"(kf)); }
-                    else kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) {
-                        if (ABL == 2 || ABL == 4) {
-                            asm volatile("" : "+v"(kf));
-                            sacc[qb][kb][s] += 1.0f;
-                        } else {
-                            sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
-                        }
-                    }
-                }
-            }
-
             // keep the -m tuple visibly alive past the QK^T MFMAs: the compiler then uses it as an UNTIED C operand for every key
             // block's first MFMA instead of copying it into the second block's accumulator (16 v_mov_b64 per 64-row tile)
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass cannot take a 16-register tuple as an asm operand)

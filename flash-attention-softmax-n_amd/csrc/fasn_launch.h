@@ -44,7 +44,7 @@ inline int launch_rc() { return hipGetLastError() == hipSuccess ? 0 : -6; }
 
 constexpr bool mode_is_vec(int MODE) { return mode_is_vector(MODE); }
 constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB) {
-    return (RING == 2 ? 6 : 4) * KT * D * 2 + (mode_is_vec(MODE) ? NW * QB * 6144 : 0) + 16;   // K/V buffers + per-wave bias / mask images + scratch word
+    return (RING == 2 ? 6 : 4) * KT * D * 2 + (mode_is_vec(MODE) ? NW * QB * 6144 : 0) + (mode_has_keypad(MODE) ? kFwdKpMaxTiles * 8 : 0);   // K/V buffers + per-wave bias / mask images + key-padding visibility words
 }
 
 // one instantiation of the forward kernel: NW waves x QB 32-row blocks per wave, staging scheme RING, accumulator seeding SEED
