@@ -15,7 +15,10 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 #endif
     switch (l.mode) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);
-        case MODE_GENERAL_B: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);   // the bias-only instantiation spills (37 VGPRs) at D = 128
+        case MODE_GENERAL_B:   // the bias-only instantiation spills (37 VGPRs) at D = 128: the bias + key-padding kernel with every key kept
+                               // (no mask image to handle: 5.32 vs 5.68 ms at (1,128,8192,128)), or the bias + mask kernel for very long key ranges
+            if ((p.Sk + KT - 1) / KT <= kFwdKpMaxTiles) return launch_fwd_one<Tag, 128, 1, MODE_BIAS_KEYPAD, 2, 8, 2, 2>(p, s);
+            return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);
         case MODE_GENERAL_M: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_M, 2, 8, 2, 2>(p, s);
         case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 128, 1, MODE_BIAS_KEYPAD, 2, 8, 2, 2>(p, s);
         default: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_SLOW, 1>(p, s);
