@@ -119,6 +119,9 @@ FASN_DEV typename E::vec8 lds_read_rowfrag(const char* tile, int row, int ks, in
 // row = (r&3) + 8*(r>>2) + 4*hi), so accumulator registers feed the other operand with no shuffle.
 // Each ds_read_b64_tr_b16: within a 16-lane group, lane i supplies the address of 4 contiguous
 // elements = tile[row0 + (i>>2)][col0 + 4*(i&3) ..]; lane i receives tile[row0 + j][col0 + i], j=0..3.
+// (Measured and rejected: keeping the lane part of the address apart from rbase * row bytes, or pinning per-tile base registers in
+// the non-unrolled D = 128 mask / bias loops. Both remove VALU instructions - 64 -> 16 per tile there, 256 -> 210 registers in the
+// unrolled kernels - and both ran 1 - 1.5 % slower: plain (4,32,8192,128) 3.72 -> 3.78 ms, causal 2.16 -> 2.19, C4 4.42 -> 4.47.)
 template <typename E, int D>
 FASN_DEV typename E::vec8 lds_read_trfrag(const char* tile, int rbase, int cblk, int lane) {
     const int hi = lane >> 5;
