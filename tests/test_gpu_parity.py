@@ -875,6 +875,43 @@ def test_key_masks_with_row_stride_zero(pkg, dev, with_bias, n, pattern, causal,
         assert (out[1] == 0).all() and (k.grad[1] == 0).all() and (v.grad[1] == 0).all()
 
 
+@pytest.mark.parametrize("D", [64, 128])
+def test_key_padding_mask_rows_that_are_not_dword_aligned(pkg, dev, D):
+    """the visibility words are built from 16-byte loads of the mask row; a row that does not start on a dword boundary (odd key
+    count, batch > 0; a sliced mask) takes the byte-load path of the same builder"""
+    dtype = torch.bfloat16
+    B, H, L, S = 3, 2, 130, 331   # row b starts at byte 331*b (+1 for the slice below)
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    store = torch.rand(B * S + 1, generator=torch.Generator().manual_seed(5)) < 0.7
+    store[1] = True
+    mask = store.to(dev)[1:].view(B, 1, 1, S)   # data pointer = base + 1
+    assert mask.data_ptr() % 4 != 0
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, attn_mask=mask)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0, attn_mask=mask)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"unaligned mask/{nm}")
+
+
+def test_key_padding_mask_longer_than_the_visibility_table(pkg, dev):
+    """the forward keeps 512 visibility words in LDS (Sk <= 32768); longer key ranges take the dense-mask general mode of the same
+    mask (fasn_api.hip) - same results"""
+    dtype = torch.bfloat16
+    B, H, L, S, D = 2, 1, 40, 32768 + 200, 64
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    mask = torch.ones(B, 1, 1, S, dtype=torch.bool)
+    mask[0, ..., 20000:] = False
+    mask[1, ..., :5000] = False
+    mask = mask.to(dev)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, attn_mask=mask)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0, attn_mask=mask)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"long key padding/{nm}")
+
+
 # ---------------------------------------------------------------- fp16 operands that a pre-scaled Q / K could overflow
 @pytest.mark.parametrize("causal", [False, True])
 def test_fp16_large_scale_does_not_overflow_the_prescaled_operand(pkg, dev, causal):
