@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     constexpr bool PSUM = SEED >= 2 && !DROP;   // fast-path row sums from the packed weights
-    constexpr bool UNR3 = RING == 2 && (D <= 64 || (FASN_UNR3_D128 && NW == 8 && !mode_is_vector(MODE)));  // direct-to-LDS loop unrolled by its three buffers
+    constexpr bool UNR3 = RING == 2 && (D <= 64 || (FASN_UNR3_D128 && NW == 8 && !mode_is_vector(MODE) && !DROP));  // direct-to-LDS loop unrolled by its three buffers
     constexpr bool UNR2 = RING == 0 && ABL == 0 && FASN_FWD_UNR2;   // single-set staging: loop unrolled by its two LDS buffers
     constexpr int NT = NW * 64;
     constexpr int BM = NW * QB * 32;

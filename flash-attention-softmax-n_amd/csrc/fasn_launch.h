@@ -67,15 +67,30 @@ int launch_fwd_cfg(const FwdParams& p, int mode, hipStream_t s) {
     return launch_fwd_one<Tag, D, QB, MODE_CAUSAL, OCC, NW, RING, SEED>(p, s);
 }
 
+#ifndef FASN_DROP_8WAVE
+#define FASN_DROP_8WAVE 1
+#endif
+#ifndef FASN_DROP_RING
+#define FASN_DROP_RING 2   // staging scheme of the plain / causal / key-padding dropout kernels (0 = register-staged, 2 = direct-to-LDS)
+#endif
 // dropout instantiations: plain, causal, key-padding, the vector mask / bias kernel (MODE_GENERAL serves all three mask / bias
 // combinations: an absent operand is a zero-range descriptor / an all-ones word) and the element-load general kernel.
 // Seeded S accumulators; the row sums stay fp32 (taken before the drop).
 template <typename Tag, int D, int QB, int OCC>
 int launch_fwd_drop(const FwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_BIAS_KEYPAD) mode = p.keypad_fallback;   // no dropout instantiation of its own: the dense-mask general mode
-    if (mode == MODE_PLAIN) return launch_fwd_one<Tag, D, QB, MODE_PLAIN, OCC, 4, 0, 1, 1>(p, s);
-    if (mode == MODE_CAUSAL) return launch_fwd_one<Tag, D, QB, MODE_CAUSAL, OCC, 4, 0, 1, 1>(p, s);
-    if (mode == MODE_KEYPAD) return launch_fwd_one<Tag, D, QB, MODE_KEYPAD, OCC, 4, 0, 1, 1>(p, s);
+    if (mode == MODE_PLAIN) {
+        if constexpr (D == 128 && FASN_DROP_8WAVE) return launch_fwd_one<Tag, D, 1, MODE_PLAIN, 2, 8, 2, 1, 1>(p, s);   // 8 waves share a K/V tile, two per SIMD
+        else return launch_fwd_one<Tag, D, QB, MODE_PLAIN, OCC, 4, FASN_DROP_RING, 1, 1>(p, s);
+    }
+    if (mode == MODE_CAUSAL) {
+        if constexpr (D == 128 && FASN_DROP_8WAVE) return launch_fwd_one<Tag, D, 1, MODE_CAUSAL, 2, 8, 2, 1, 1>(p, s);   // 8 waves share a K/V tile, two per SIMD
+        else return launch_fwd_one<Tag, D, QB, MODE_CAUSAL, OCC, 4, FASN_DROP_RING, 1, 1>(p, s);
+    }
+    if (mode == MODE_KEYPAD) {
+        if constexpr (D == 128 && FASN_DROP_8WAVE) return launch_fwd_one<Tag, D, 1, MODE_KEYPAD, 2, 8, 2, 1, 1>(p, s);   // 8 waves share a K/V tile, two per SIMD
+        else return launch_fwd_one<Tag, D, QB, MODE_KEYPAD, OCC, 4, FASN_DROP_RING, 1, 1>(p, s);
+    }
     if (mode == MODE_GENERAL || mode == MODE_GENERAL_B || mode == MODE_GENERAL_M) {
         if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_GENERAL, 2, 8, 2, 1, 1>(p, s);
         else return launch_fwd_one<Tag, D, 1, MODE_GENERAL, (D == 32 ? 1 : 2), 4, 0, 1, 1>(p, s);
