@@ -10,7 +10,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasn.so")
 
-FASN_ABI_VERSION = 3
+FASN_ABI_VERSION = 4
+FASN_BWD_ONE_PASS = 1
 FASN_DTYPE_F16, FASN_DTYPE_BF16, FASN_DTYPE_F32 = 0, 1, 2
 FASN_BIAS_NONE, FASN_BIAS_SAME, FASN_BIAS_F32 = 0, 1, 2
 
@@ -46,6 +47,7 @@ class BwdArgs(Structure):
         ("dout", View4), ("dq", View4), ("dk", View4), ("dv", View4),
         ("delta", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("dbias", View4),
+        ("flags", c_int32),
     ]
 
 

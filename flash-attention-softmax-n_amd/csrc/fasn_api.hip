@@ -280,9 +280,22 @@ int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int varian
 }
 #endif
 
+// One-pass backward (fasn_bwd_fused.h): opt-in (it measures slower than the split kernels), and only where it exists
+static bool bwd_fused_applies(const fasn_bwd_args* a, const FwdParams& p, const FwdLaunch& l) {
+    if (!(a->flags & FASN_BWD_ONE_PASS)) return false;
+    if (l.dtype == FASN_DTYPE_F32 || l.D != 64) return false;
+    if (l.mode != MODE_PLAIN && l.mode != MODE_CAUSAL) return false;
+    if (p.drop_thr != 0 || p.kvg > 1) return false;
+    return true;
+}
+static size_t bwd_fused_bytes(const fasn_bwd_args* a) { return (size_t)a->fwd.B * a->fwd.H * a->fwd.Sq * a->fwd.D * sizeof(float); }
+
 size_t fasn_bwd_workspace_bytes(const fasn_bwd_args* args) {
-    (void)args;
-    return 0;
+    if (args == nullptr) return 0;
+    FwdParams p;
+    FwdLaunch l;
+    if (build_fwd(&args->fwd, p, l)) return 0;
+    return bwd_fused_applies(args, p, l) ? bwd_fused_bytes(args) : 0;
 }
 
 int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
@@ -312,6 +325,11 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
         if (qb <= 0 || db <= 0 || qb >= (1ll << 31) || db >= (1ll << 31)) return FASN_EINVAL;
         p.qbytes = (unsigned)qb;
         p.dobytes = (unsigned)db;
+    }
+    p.dqacc = nullptr;
+    if (bwd_fused_applies(a, fp, l) && a->workspace != nullptr && a->workspace_bytes >= bwd_fused_bytes(a)) {
+        if (reinterpret_cast<uintptr_t>(a->workspace) % 16) return FASN_EALIGN;
+        p.dqacc = static_cast<float*>(a->workspace);
     }
     p.dbias = nullptr;
     p.dbias_vec = 0;

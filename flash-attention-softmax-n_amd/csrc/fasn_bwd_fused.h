@@ -1,0 +1,452 @@
+// fasn_bwd_fused.h — the backward as ONE pass over the score blocks: 5 GEMMs (S, dP, dV, dK, dQ) instead of the 7 the
+// deterministic dQ + dK/dV split executes (reference: one kernel too, flash_attn_triton.py:199-226, dq load-add-store at :223-226).
+//
+// A workgroup owns 512 keys of one (b,h) (8 waves x 64 keys, two waves per SIMD, one workgroup per CU) and walks the 32-row
+// q-tiles that can see them. Per tile and wave, with a lane owning a key column (same orientation as fasn_bwd_dkdv_kernel):
+//
+//   S  = Q K'^T   (A: Q rows from LDS, B: K' = K*scale*log2e from the workgroup's K' image in LDS; seeded with -LSE*log2e)
+//   dP = dO V^T   (A: dO rows from LDS, B: V fragments in registers; seeded with -delta)
+//   P = exp2(S), dS = P o dP'          16-bit, in the accumulator layout [row][key]
+//   dV^T += dO^T P,  dK^T += Q^T dS    (fp32 accumulators in registers for the whole kernel)
+//   dS -> LDS image [512 keys][32 rows] (the transpose the fifth GEMM needs: its contraction runs over KEYS, the lane dimension)
+//
+// and, once every wave has published its part of the tile's dS:
+//
+//   dQ[32 rows][64] = dS[32][512 keys] K'[512][64]: eight 16 x 16 output pieces, one per wave, 16 x v_mfma_f32_16x16x32 each,
+//   both operands by transposing LDS reads (dS image / K' image), then 4 fp32 atomic adds per lane into the fp32 dQ
+//   accumulator [B,H,Sq,64] in the caller's workspace (hardware global_atomic_add_f32: measured 1.35 TB/s of partials,
+//   tools/ubench_atomic.cpp; one partial per element and 512-key block: Sk/512 x |dQ| x 4 bytes per launch).
+//
+// fasn_bwd_dq_convert_kernel rounds the accumulator to the output type. The order of the atomic adds is not fixed, so dQ is
+// reproducible only to fp32 rounding of a sum of Sk/512 terms (dK / dV are deterministic): callers that need bit-exact
+// reruns set FASN_BWD_DETERMINISTIC and get the split kernels.
+//
+// Schedule: one barrier per tile; every wave runs [dQ GEMM of tile t-1] [S, dP, element pass, dS -> LDS] [dV, dK] on tile t.
+// (Measured and rejected: a ping-pong of the two waves of a SIMD - waves 0-3 in the S / dP / element phase while waves 4-7
+// run dV / dK / dQ, two barriers per tile - 2.26 against 1.92 ms at (8,16,4096,64): the phases are bound by their own
+// LDS-read -> MFMA dependency chains, not by a shared unit, so pairing them only adds the second barrier.)
+//
+// K' is rounded to the operand type after scaling (as in every vector kernel here); dQ = scale dS K = ln2 dS K'.
+// D = 64 only (the BASELINE head dim of four of the five configs); plain and causal.
+#pragma once
+#include "fasn_bwd_kernel.h"
+
+namespace fasn {
+
+constexpr int FQT = 32;     // query rows per tile of the fused kernel
+constexpr int FBN = 512;    // keys per workgroup
+
+// K' image [512][64] 16-bit: 128-byte rows, 16-byte chunk c of row r at chunk c ^ fk_swz(r). Conflict free for (1) the
+// ds_read_b128 row fragments of the S GEMM (16-lane service groups {0-3,12-15,20-27}, {4-11,16-19,28-31}: rows of equal
+// parity get 8 distinct values) and (2) the 16x16x32 operand pattern of the dQ GEMM (per half-wave: rows {0..3} u {8..11},
+// 32 bytes each: rows r, r+2, r+8, r+10 land in four different 32-byte quarters of the 128-byte line).
+FASN_DEV int fk_swz(int row) { return ((row & 2) << 1) | ((row >> 2) & 2) | ((row >> 2) & 1); }
+FASN_DEV int fk_off(int row, int chunk) { return row * 128 + ((chunk ^ fk_swz(row)) << 4); }
+// dS image [512 keys][32 rows] 16-bit: 64-byte rows of eight 8-byte pieces (4 query rows each), piece q of key k at
+// q ^ ((k >> 1) & 7): the 16 lanes of a ds_write_b64 service group (16 consecutive keys, one piece index) hit 16 different
+// 8-byte slots of 128 bytes, and the transposing reads of the dQ GEMM (rows {0..3} u {8..11}, four pieces each) all 64 banks.
+FASN_DEV int fds_off(int key, int piece) { return key * 64 + ((piece ^ ((key >> 1) & 7)) << 3); }
+
+template <typename Tag>
+struct MF16;
+template <>
+struct MF16<bf16_tag> {
+    static FASN_DEV f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct MF16<f16_tag> {
+    static FASN_DEV f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+// two transposing reads = one 16x16x32 operand: lane (i = lane & 15, g = lane >> 4) gets element i of rows p0[0..3], p1[0..3]
+template <typename E>
+FASN_DEV typename E::vec8 tr_pair(const char* p0, const char* p1) {
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p0));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p1));
+    s16x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    typename E::vec8 r;
+    __builtin_memcpy(&r, &ab, 16);
+    return r;
+}
+
+constexpr int fused_smem_bytes() { return 4 * FQT * 64 * 2 + 4 * FQT * 4 + 2 * FBN * FQT * 2 + FBN * 64 * 2; }
+
+// ABL (developer ablations, never dispatched by the ABI): 1 = no atomics, 2 = no dQ GEMM, 3 = no dQ GEMM and no dS image
+template <typename Tag, int MODE, int ABL = 0>
+__global__ void __launch_bounds__(512, 2) fasn_bwd_fused_kernel(const BwdParams bp) {
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "fused backward: plain and causal");
+    using E = ET<Tag>;
+    using vec8 = typename E::vec8;
+    const FwdParams& p = bp.f;
+    constexpr int D = 64, KS = 4, DB = 2, KB = 2;
+    constexpr int QTILE = FQT * D * 2;     // 4 KiB
+    constexpr int DSBUF = FBN * FQT * 2;   // 32 KiB
+    constexpr bool causal = MODE == MODE_CAUSAL;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsQ = smem;                                                  // [2][QTILE]
+    char* const ldsDO = smem + 2 * QTILE;                                     // [2][QTILE]
+    float* const ldsLse = reinterpret_cast<float*>(smem + 4 * QTILE);         // [2][FQT]  -lse*log2e
+    float* const ldsDlt = ldsLse + 2 * FQT;                                   // [2][FQT]  -delta
+    char* const ldsDS = smem + 4 * QTILE + 4 * FQT * 4;                       // [2][DSBUF]
+    char* const ldsK = ldsDS + 2 * DSBUF;                                     // [512][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+
+    int bh, kblk;
+    block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
+    const int b = bh / p.H, h = bh % p.H;
+    const int kg0 = kblk * FBN;             // first key of the workgroup
+    const int kw0 = kg0 + wave * (KB * 32);   // first key of this wave
+    const int coff = p.Sk - p.Sq;
+
+    const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
+    const char* kbase = p.k + (b * p.ks[0] + h * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + h * p.vs[1]) * 2;
+    const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2;
+    const float* lsebase = p.lse + (int64_t)bh * p.Sq;
+    const float* dltbase = bp.delta + (int64_t)bh * p.Sq;
+    float* const dqa = bp.dqacc + (int64_t)bh * p.Sq * D;
+
+    const int ntq = (p.Sq + FQT - 1) / FQT;
+    int tq0 = 0;
+    if (causal) {
+        const int first_row = kg0 - coff;   // first row that sees the first key of the block
+        tq0 = first_row <= 0 ? 0 : first_row / FQT;
+    }
+
+    // ---- Q / dO tiles straight to LDS: waves 0-3 bring the Q tile (one 16-byte piece per thread), waves 4-7 the dO tile
+    const int tsel = wave >> 2;
+    const u32x4 trw = tsel == 0 ? make_rsrc_words(qbase, bp.qbytes) : make_rsrc_words(dobase, bp.dobytes);
+    const int trs = tsel == 0 ? (int)p.qs[2] : (int)bp.dos[2];
+    unsigned tvoff;
+    {
+        const int ci = tid & 255, row = ci >> 3, ch = (ci & 7) ^ swz_f<64>(row);
+        tvoff = (unsigned)(row * trs * 2 + ch * 16);
+    }
+    const uint32_t tdst = lds_addr(smem) + tsel * (2 * QTILE) + (wave & 3) * 1024;
+    auto tile_dma = [&](int tq, int buf) { lds_dma16(trw, __builtin_amdgcn_readfirstlane(tdst + buf * QTILE), tvoff, tq * FQT * trs * 2); };
+    float stL = 0.f, stX = 0.f;
+    auto stats_gload = [&](int row0) {
+        if (tid < FQT) {
+            const int gr = row0 + tid;
+            float l = INFINITY, x = 0.f;
+            if (gr < p.Sq) {
+                l = lsebase[gr];
+                x = dltbase[gr];
+            }
+            stL = (l == -INFINITY || l == INFINITY) ? -INFINITY : -l * kLog2e;   // a row without weights: every P = exp2(-inf) = 0
+            stX = -x;
+        }
+    };
+    auto stats_lstore = [&](int buf) {
+        if (tid < FQT) {
+            ldsLse[buf * FQT + tid] = stL;
+            ldsDlt[buf * FQT + tid] = stX;
+        }
+    };
+    if (tq0 < ntq) {
+        tile_dma(tq0, 0);
+        stats_gload(tq0 * FQT);
+    }
+
+    // ---- K' image: 512 keys x 8 chunks, 8 per thread; rows past Sk read back as zeros (range-checked descriptor)
+    {
+        const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase), 0, p.kbytes, 0x00020000);
+        u32x4 kr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ci = tid + i * 512, row = ci >> 3, ch = ci & 7;
+            kr[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, (unsigned)(row * (int)p.ks[2] * 2 + ch * 16), kg0 * (int)p.ks[2] * 2, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ci = tid + i * 512, row = ci >> 3, ch = ci & 7;
+            uint16_t hk[8];
+            __builtin_memcpy(hk, &kr[i], 16);
+            f32x8 f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hk[e]) * p.c;
+            const vec8 kv = E::cvt8(f);
+            u32x4 w;
+            __builtin_memcpy(&w, &kv, 16);
+            *LDS_PTR(u32x4, ldsK + fk_off(row, ch)) = w;
+        }
+    }
+    // V fragments of this wave's keys (B operand: col = key = lane&31, k = 8 contiguous features)
+    vec8 vf[KB][KS];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int key = kw0 + kb * 32 + l31;
+        const bool ok = key < p.Sk;
+        const char* rv = vbase + (int64_t)key * p.vs[2] * 2 + hi * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 c = {0u, 0u, 0u, 0u};
+            if (ok) c = gload16(rv + s * 32);
+            __builtin_memcpy(&vf[kb][s], &c, 16);
+        }
+    }
+    f32x16 dkacc[KB][DB], dvacc[KB][DB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[kb][d][r] = 0.f;
+                dvacc[kb][d][r] = 0.f;
+            }
+    if (tq0 < ntq) stats_lstore(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) retire_loads(vf[kb][s]);
+
+    // this wave's output piece of the dQ GEMM: rows q0.. x features d0.. of the tile
+    const int q0 = 16 * (wave & 1), d0 = 16 * (wave >> 1);
+    // Lane-dependent LDS offsets that cannot fold into instruction immediates (the XOR swizzles) are recomputed per tile from an
+    // opaque copy of the lane id instead of living in registers across the loop: 12 address registers are what the kernel does
+    // not have (dK / dV accumulators + V fragments = 160 of 256), and a spilled loop invariant comes back through scratch with a
+    // vmcnt(0) wait that also drains the Q / dO requests and the atomics in flight.
+    auto opaque_lane = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+
+    // dQ of tile `tq` from the dS image in buffer `dsb`: out[16 rows][16 features] over the visible key steps, then atomics
+    auto dq_gemm = [&](const int tq, const int dsb) __attribute__((always_inline)) {
+        const int r0 = tq * FQT;
+        const char* ds = ldsDS + dsb * DSBUF;
+        const int ln = opaque_lane();
+        const int i16 = ln & 15, g4 = ln >> 4;
+        const int krow = 8 * g4 + (i16 >> 2);   // key of the first transposing read inside a 32-key step (second read: + 4)
+        const int a_off0 = fds_off(krow, (q0 >> 2) + (i16 & 3)), a_off1 = fds_off(krow + 4, (q0 >> 2) + (i16 & 3));
+        const int b_off0 = fk_off(krow, (d0 >> 3) + ((i16 & 3) >> 1)) + (i16 & 1) * 8, b_off1 = fk_off(krow + 4, (d0 >> 3) + ((i16 & 3) >> 1)) + (i16 & 1) * 8;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (causal) {
+            // waves whose 64 keys no row of the tile sees wrote nothing: walk only the key steps of the others
+            // (rows past Sq see nothing: without the clamp a ragged last tile could reach the unwritten part of a wave whose keys lie past Sk)
+            const int lastvis = min(r0 + FQT, p.Sq) - 1 + coff - kg0;
+            const int nw = lastvis < 0 ? 0 : min(8, lastvis / 64 + 1);
+            for (int w = 0; w < nw; ++w) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int ks = 2 * w + s2;
+                    const vec8 a = tr_pair<E>(ds + a_off0 + ks * 2048, ds + a_off1 + ks * 2048);
+                    const vec8 bb = tr_pair<E>(ldsK + b_off0 + ks * 4096, ldsK + b_off1 + ks * 4096);
+                    acc = MF16<Tag>::mfma(a, bb, acc);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const vec8 a = tr_pair<E>(ds + a_off0 + ks * 2048, ds + a_off1 + ks * 2048);
+                const vec8 bb = tr_pair<E>(ldsK + b_off0 + ks * 4096, ldsK + b_off1 + ks * 4096);
+                acc = MF16<Tag>::mfma(a, bb, acc);
+            }
+        }
+        float* dst = dqa + (int64_t)(r0 + q0 + 4 * g4) * D + d0 + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r0 + q0 + 4 * g4 + r < p.Sq && (ABL != 1 || acc[r] == 123.456f)) unsafeAtomicAdd(dst + r * D, acc[r] * kLn2);
+    };
+
+
+    // ---- phase X of tile tq (tile buffer TB, dS buffer dsb): S, dP, element pass, dS image; leaves P / dS fragments for phase Y
+    auto phase_x = [&](const int tq, auto TB_, const int dsb, vec8 (&pfr)[KB][2], vec8 (&dsfr)[KB][2]) __attribute__((always_inline)) -> bool {
+        constexpr int tb = decltype(TB_)::value;
+        const int r0 = tq * FQT;
+        const char* tQ = ldsQ + tb * QTILE;
+        const char* tD = ldsDO + tb * QTILE;
+        const float* tL = ldsLse + tb * FQT;
+        const float* tX = ldsDlt + tb * FQT;
+        char* const dsw = ldsDS + dsb * DSBUF;
+        // LDS write offsets of this lane's dS pieces: register group g (rows 8g + 4hi + 0..3) of key block kb -> piece 2g + hi
+        int ws_off[4];
+        {
+            const int ln = opaque_lane();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ws_off[g] = fds_off(wave * 64 + (ln & 31), 2 * g + (ln >> 5));
+        }
+        // wave-uniform classification of (this q tile) x (this wave's keys [kw0, kw0 + 64))
+        bool skip = kw0 >= p.Sk, need_mask = false;
+        if (causal) {
+            skip = skip || (r0 + FQT - 1 + coff) < kw0;            // even the last row sees none of my keys
+            need_mask = (r0 + coff) < (kw0 + KB * 32 - 1);         // the first row does not see all my keys
+        }
+        if (r0 + FQT > p.Sq || kw0 + KB * 32 > p.Sk) need_mask = true;
+        if (!skip) {
+            // one 32-key block at a time (S and dP accumulators of ONE block live: the dK / dV accumulators and the V fragments
+            // already take 160 of the 256 registers); the Q / dO row fragments are read again for the second block
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 sacc, pacc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 a = *LDS_PTR(const f32x4, tL + 8 * g + 4 * hi);
+                    const f32x4 c = *LDS_PTR(const f32x4, tX + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sacc[4 * g + e] = a[e];
+                        pacc[4 * g + e] = c[e];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const vec8 qa = lds_read_rowfrag<E, D>(tQ, l31, s, hi);
+                    const vec8 da = lds_read_rowfrag<E, D>(tD, l31, s, hi);
+                    u32x4 raw = *LDS_PTR(const u32x4, ldsK + fk_off(wave * 64 + kb * 32 + l31, 2 * s + hi));
+                    vec8 kf;
+                    __builtin_memcpy(&kf, &raw, 16);
+                    sacc = E::mfma(qa, kf, sacc);
+                    pacc = E::mfma(da, vf[kb][s], pacc);
+                }
+                const int key = kw0 + kb * 32 + l31;
+                auto elems = [&](auto MASKED) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float pv = fast_exp2(sacc[r]);
+                        if (decltype(MASKED)::value) {
+                            const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const bool show = (key < p.Sk) && (row < p.Sq) && (!causal || key <= row + coff);
+                            pv = show ? pv : 0.f;
+                        }
+                        sacc[r] = pv;
+                        pacc[r] = pv * pacc[r];
+                    }
+                };
+                if (need_mask) elems(std::true_type{});
+                else elems(std::false_type{});
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    f32x8 x, y;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        x[e] = sacc[8 * t2 + e];
+                        y[e] = pacc[8 * t2 + e];
+                    }
+                    pfr[kb][t2] = E::cvt8(x);
+                    dsfr[kb][t2] = E::cvt8(y);
+                    // dS to the image: registers 8*t2 .. +3 = rows 16*t2 + 4hi + 0..3 (piece 4*t2 + hi), .. +4..7 = rows + 8 (piece + 2)
+                    u32x4 w;
+                    __builtin_memcpy(&w, &dsfr[kb][t2], 16);
+                    if (ABL != 3) {
+                        *LDS_PTR(u32x2, dsw + ws_off[2 * t2] + kb * 2048) = u32x2{w[0], w[1]};
+                        *LDS_PTR(u32x2, dsw + ws_off[2 * t2 + 1] + kb * 2048) = u32x2{w[2], w[3]};
+                    }
+                }
+            }
+        } else if (!causal) {
+            // (plain mode: the dQ GEMM walks all 16 key steps - a wave whose keys lie past Sk clears its part of the image)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *LDS_PTR(u32x2, dsw + ws_off[g] + kb * 2048) = u32x2{0u, 0u};
+        }
+        return skip;
+    };
+    // ---- phase Y: dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+    auto phase_y = [&](auto TB_, const vec8 (&pfr)[KB][2], const vec8 (&dsfr)[KB][2]) __attribute__((always_inline)) {
+        constexpr int tb = decltype(TB_)::value;
+        const char* tQ = ldsQ + tb * QTILE;
+        const char* tD = ldsDO + tb * QTILE;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const vec8 dot = lds_read_trfrag<E, D>(tD, 16 * t2, d, lane);
+                const vec8 qt = lds_read_trfrag<E, D>(tQ, 16 * t2, d, lane);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    dvacc[kb][d] = E::mfma(dot, pfr[kb][t2], dvacc[kb][d]);
+                    dkacc[kb][d] = E::mfma(qt, dsfr[kb][t2], dkacc[kb][d]);
+                }
+            }
+    };
+
+    using TB0 = std::integral_constant<int, 0>;
+    using TB1 = std::integral_constant<int, 1>;
+    vec8 pfr[KB][2], dsfr[KB][2];
+    // one barrier per tile: [requests for tile t+1] [dQ GEMM of tile t-1: its atomics then have the whole tile to retire] [X(t)] [Y(t)]
+    auto iter = [&](const int tq, auto TB_, auto TBN_) __attribute__((always_inline)) {
+        constexpr int dsb = decltype(TB_)::value;   // dS buffer = tile buffer index
+        if (tq + 1 < ntq) {   // the buffers of tile t+1 were released by the barrier that ended tile t-1
+            tile_dma(tq + 1, decltype(TBN_)::value);
+            stats_gload((tq + 1) * FQT);
+        }
+        if (tq > tq0 && ABL < 2) dq_gemm(tq - 1, dsb ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool skip = phase_x(tq, TB_, dsb, pfr, dsfr);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!skip) phase_y(TB_, pfr, dsfr);
+        if (tq + 1 < ntq) stats_lstore(decltype(TBN_)::value);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next Q / dO tile has landed (and this tile's atomics retired)
+        __syncthreads();
+    };
+    for (int tq = tq0; tq < ntq; tq += 2) {
+        iter(tq, TB0{}, TB1{});
+        if (tq + 1 < ntq) iter(tq + 1, TB1{}, TB0{});
+    }
+    if (tq0 < ntq && ABL < 2) dq_gemm(ntq - 1, (ntq - 1 - tq0) & 1);
+
+    char* dkbase = bp.dk + (b * bp.dks[0] + h * bp.dks[1]) * 2;
+    char* dvbase = bp.dv + (b * bp.dvs[0] + h * bp.dvs[1]) * 2;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int key = kw0 + kb * 32 + l31;
+        if (key < p.Sk) {
+            char* rk = dkbase + (int64_t)key * bp.dks[2] * 2;
+            char* rv = dvbase + (int64_t)key * bp.dvs[2] * 2;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 x, y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = dkacc[kb][d][4 * g + e] * bp.scale;
+                        y[e] = dvacc[kb][d][4 * g + e];
+                    }
+                    typename E::vec4 xk = E::cvt4(x), yv = E::cvt4(y);
+                    u32x2 ra, rb;
+                    __builtin_memcpy(&ra, &xk, 8);
+                    __builtin_memcpy(&rb, &yv, 8);
+                    gstore8(rk + (d * 32 + 8 * g + 4 * hi) * 2, ra);
+                    gstore8(rv + (d * 32 + 8 * g + 4 * hi) * 2, rb);
+                }
+        }
+    }
+}
+
+// dq[b,h,i,:] = round(dqacc[b,h,i,:]): 8 features per thread (32 bytes in, 16 bytes out)
+template <typename Tag, int D>
+__global__ void __launch_bounds__(256) fasn_bwd_dq_convert_kernel(const BwdParams bp) {
+    using E = ET<Tag>;
+    constexpr int LPR = D / 8;
+    const FwdParams& p = bp.f;
+    const int64_t rows = (int64_t)p.B * p.H * p.Sq;
+    const int64_t gr = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    if (gr >= rows) return;
+    const int i = (int)(gr % p.Sq);
+    const int bh = (int)(gr / p.Sq);
+    const int b = bh / p.H, h = bh % p.H;
+    const f32x4* src = reinterpret_cast<const f32x4*>(bp.dqacc + gr * D + sub * 8);
+    const f32x4 a = src[0], c = src[1];
+    f32x8 f = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+    const typename E::vec8 v = E::cvt8(f);
+    u32x4 w;
+    __builtin_memcpy(&w, &v, 16);
+    gstore16(bp.dq + (b * bp.dqs[0] + h * bp.dqs[1] + (int64_t)i * bp.dqs[2]) * 2 + sub * 16, w);
+}
+
+}  // namespace fasn

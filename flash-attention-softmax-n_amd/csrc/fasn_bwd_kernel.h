@@ -36,6 +36,7 @@ struct BwdParams {
     char* dbias;       // optional: dS written densely [B,H,Sq,Sk] (element type of q), key stride 1; nullptr = not wanted
     int64_t dbs[3];
     int dbias_vec;     // rows 16-byte aligned: 8 keys per store on the vector path
+    float* dqacc;      // fused backward (fasn_bwd_fused.h): fp32 dQ accumulator [B,H,Sq,D] in the caller's workspace; nullptr = split kernels
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -108,6 +108,21 @@ def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal, dropout
     a.rng_state = None if rng is None else rng.data_ptr()
 
 
+_BACKWARD_PLAN = "split"
+
+
+def set_backward_plan(plan: str) -> str:
+    """Select the backward plan of fasn_bwd: "split" (default: dQ kernel + dK/dV kernel, 7 GEMMs, deterministic) or "one_pass"
+    (one kernel, 5 GEMMs, dQ accumulated with fp32 atomics - the structure of the reference's flash_attn_triton.py:199-226; exists
+    for D = 64 without mask / bias / dropout / grouped K/V, falls back to "split" elsewhere; measured slower on MI355X).
+    Returns the previous plan."""
+    global _BACKWARD_PLAN
+    if plan not in ("split", "one_pass"):
+        raise ValueError('plan must be "split" or "one_pass"')
+    prev, _BACKWARD_PLAN = _BACKWARD_PLAN, plan
+    return prev
+
+
 class _FlashAttentionSoftmaxN(torch.autograd.Function):
     """autograd glue; same role as _FlashAttentionN (flash_attn_triton.py:241-336)."""
 
@@ -149,6 +164,9 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         a.delta = delta.data_ptr()
         a.workspace = None
         a.workspace_bytes = 0
+        # plan: split kernels (default, deterministic) or the opt-in one-pass backward (fp32 atomics for dQ; never under
+        # torch.use_deterministic_algorithms(True)) - see set_backward_plan()
+        a.flags = _lib.FASN_BWD_ONE_PASS if (_BACKWARD_PLAN == "one_pass" and not torch.are_deterministic_algorithms_enabled()) else 0
         # gradient of attn_bias: the kernel writes dS densely; autograd sums it over the dimensions the caller's bias broadcasts
         # (the expand / unsqueeze / dtype cast in _attention are ordinary autograd ops)
         dbias = None
@@ -156,6 +174,10 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
             dbias = torch.zeros((B, H, L, S), dtype=q.dtype, device=q.device)   # tiles the causal walk skips are never written
             a.dbias = _view4(dbias)
         with torch.cuda.device(q.device):
+            ws_bytes = lib.fasn_bwd_workspace_bytes(a)   # > 0: one-pass backward, the fp32 dQ accumulator is ours to provide
+            if ws_bytes:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+                a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
             _lib.check(lib.fasn_bwd(a, _stream_ptr(q.device)), "fasn_bwd")
         if dbias is not None and dbias.dtype != bias.dtype:
             dbias = dbias.to(bias.dtype)

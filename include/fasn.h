@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FASN_ABI_VERSION 3
+#define FASN_ABI_VERSION 4
 
 /* error codes */
 #define FASN_OK 0
@@ -100,8 +100,19 @@ typedef struct fasn_fwd_args {
  * Backward. Replaces _bwd_preprocess + _bwd_kernel (flash_attn_triton.py:316-335), with the
  * softmax_n-correct LSE (the reference's Triton backward drops n).
  * dq/dk/dv are written (not accumulated) in `dtype`. `delta` is a [B,H,Sq] fp32 scratch the
- * caller provides; `workspace` must hold fasn_bwd_workspace_bytes() bytes (may be 0).
+ * caller provides.
+ *
+ * Two plans. (1) Split (the default; deterministic): a dQ kernel and a dK/dV kernel that each recompute S and dP, 7 GEMMs for
+ * the 5 of the algorithm, no workspace. (2) One pass (ABI 4, opt-in with FASN_BWD_ONE_PASS in `flags`; D = 64, fp16 / bf16,
+ * no mask / bias / dropout / grouped K/V): the dK/dV workgroups also form dQ = dS K per score block - 5 GEMMs, the structure
+ * of the reference's single kernel (flash_attn_triton.py:199-226) - and add their partial dQ tiles into an fp32 accumulator
+ * [B,H,Sq,D] with hardware atomics (the reference's load-add-store at :223-226); a last pass rounds it to `dtype`. The
+ * accumulator is the caller's `workspace`: fasn_bwd_workspace_bytes() returns its size when plan (2) is requested and
+ * applies to `args` (else 0); a NULL or too small workspace silently selects plan (1). With plan (2) dQ is reproducible to
+ * fp32 rounding of a sum of ceil(Sk/512) terms, not bit for bit; dK and dV are deterministic in both plans. Plan (2) is
+ * NOT the default because it measures slower on MI355X (1.92 against 1.78 ms at (8,16,4096,64)).
  */
+#define FASN_BWD_ONE_PASS 1 /* fasn_bwd_args.flags: take the one-pass backward where it exists */
 typedef struct fasn_bwd_args {
     fasn_fwd_args fwd; /* same views as forward; o and lse are inputs here */
     fasn_view4 dout;   /* [B,H,Sq,Dv] */
@@ -113,6 +124,7 @@ typedef struct fasn_bwd_args {
     size_t workspace_bytes;
     fasn_view4 dbias;  /* optional out (ABI 2): gradient of the additive bias = dS, dense [B,H,Sq,Sk] in `dtype`, key stride 1;
                           ptr NULL = not wanted. Needs fwd.bias; the caller sums over the dimensions its bias broadcasts. */
+    int32_t flags;     /* ABI 4: FASN_BWD_* bits, 0 = default */
 } fasn_bwd_args;
 
 int fasn_abi_version(void);

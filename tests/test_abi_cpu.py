@@ -38,7 +38,7 @@ def test_library_exports_nothing_but_the_header(pkg):
 
 def test_abi_version_and_strerror(pkg):
     lib = pkg._lib.load()
-    assert lib.fasn_abi_version() == 3
+    assert lib.fasn_abi_version() == 4
     assert lib.fasn_strerror(0) == b"ok"
     for code in range(-8, 0):
         assert len(lib.fasn_strerror(code)) > 5

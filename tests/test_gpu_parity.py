@@ -203,6 +203,77 @@ def test_golden_g5f_backward_at_full_grid(pkg, dev, golden_dir, cfg):
             assert err <= lim, f"{cfg} head {hi} {name}: max-abs {err:.3e} vs fp32 slow_attention_n > {lim:.3e}"
 
 
+# ---------------------------------------------------------------- the opt-in one-pass backward (5 GEMMs, dQ by fp32 atomics)
+@pytest.fixture
+def one_pass_plan(pkg):
+    prev = pkg.set_backward_plan("one_pass")
+    yield
+    pkg.set_backward_plan(prev)
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "m0", "c5"])
+def test_golden_g5f_backward_one_pass_plan(pkg, dev, golden_dir, one_pass_plan, cfg):
+    """The D = 64 BASELINE configs at their full grid through fasn_bwd's one-pass plan (csrc/fasn_bwd_fused.h; the structure of the
+    reference's single backward kernel, flash_attn_triton.py:199-226): same fixtures and the same two gates as the split plan."""
+    test_golden_g5f_backward_at_full_grid(pkg, dev, golden_dir, cfg)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("L,S", [(1024, 1024), (100, 77), (3, 5), (300, 200), (1100, 1300), (1300, 1100), (33, 1000), (513, 1537)])
+def test_one_pass_plan_vs_oracle_and_split(pkg, dev, one_pass_plan, L, S, causal, dtype):
+    """Ragged sizes, L != S (bottom-right causal alignment), several 512-key blocks per head, n in {0, 1}: the one-pass plan against
+    the oracle, and its dQ against the split plan's (they may differ by fp32 summation order only: far below one 16-bit ulp)."""
+    B, H, D = 2, 2, 64
+    n = 1.0 if (L % 2 or L > S) else 0.0   # (n = 0 with fully hidden rows, causal L > S: the oracle's autograd is 0/0 there)
+    q, k, v = (_rand((B, H, s_, D), dtype, dev, sd).requires_grad_() for s_, sd in ((L, 11), (S, 12), (S, 13)))
+    do = _rand((B, H, L, D), dtype, dev, 14, std=1.0)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=n, is_causal=causal)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"one-pass {nm}")
+    one = [t.grad.clone() for t in (q, k, v)]
+    pkg.set_backward_plan("split")
+    for t in (q, k, v):
+        t.grad = None
+    pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal).backward(do)
+    assert torch.equal(one[1], k.grad) or (one[1].float() - k.grad.float()).abs().max() <= REL_TRUE[dtype] * k.grad.float().abs().max()
+    ulp = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * max(q.grad.float().abs().max().item(), 1e-3)
+    assert (one[0].float() - q.grad.float()).abs().max().item() <= 2 * ulp
+
+
+def test_one_pass_plan_is_opt_in_and_falls_back(pkg, dev):
+    """Default plan = split (no workspace asked for); the one-pass plan exists for D = 64 plain / causal only and everything else
+    (other head dims, masks, bias, dropout, grouped K/V, deterministic mode) silently takes the split kernels."""
+    from flash_attention_softmax_n_amd import _lib
+    from flash_attention_softmax_n_amd.flash_attn import BwdArgs, _fill_fwd
+    lib = _lib.load()
+
+    def ws_bytes(D, flags, mask=None, Hkv=2):
+        q = torch.zeros(1, 2, 64, D, dtype=torch.bfloat16, device=dev)
+        k = torch.zeros(1, Hkv, 64, D, dtype=torch.bfloat16, device=dev)
+        lse = torch.zeros(1, 2, 64, dtype=torch.float32, device=dev)
+        a = BwdArgs()
+        _fill_fwd(a.fwd, q, k, k, q, lse, mask, None, 1.0, 0.125, False)
+        a.flags = flags
+        return lib.fasn_bwd_workspace_bytes(a)
+
+    assert ws_bytes(64, 0) == 0
+    assert ws_bytes(64, _lib.FASN_BWD_ONE_PASS) == 1 * 2 * 64 * 64 * 4
+    assert ws_bytes(128, _lib.FASN_BWD_ONE_PASS) == 0 and ws_bytes(32, _lib.FASN_BWD_ONE_PASS) == 0
+    assert ws_bytes(64, _lib.FASN_BWD_ONE_PASS, Hkv=1) == 0
+    m = torch.ones(1, 2, 64, 64, dtype=torch.uint8, device=dev)
+    assert ws_bytes(64, _lib.FASN_BWD_ONE_PASS, mask=m) == 0
+    prev = pkg.set_backward_plan("one_pass")
+    try:
+        q, k, v = (_rand((1, 2, 128, 128), torch.bfloat16, dev, s).requires_grad_() for s in (1, 2, 3))
+        pkg.flash_attention_n(q, k, v, softmax_n_param=1.0).sum().backward()   # D = 128: split kernels
+        assert torch.isfinite(q.grad.float()).all()
+    finally:
+        pkg.set_backward_plan(prev)
+
+
 # ---------------------------------------------------------------- masks, bias, layouts, edge cases
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("D", [32, 64, 128])

@@ -197,6 +197,8 @@ static void reference_head(const Problem& P, const Host& h, int b, int hh, bool 
 struct Dev {
     void *q = 0, *k = 0, *v = 0, *o = 0, *dout = 0, *dq = 0, *dk = 0, *dv = 0, *mask = 0, *bias = 0;
     float *lse = 0, *delta = 0;
+    void* ws = 0;
+    size_t ws_bytes = 0;
 };
 template <typename T>
 static void* upload(const std::vector<T>& v) {
@@ -226,7 +228,7 @@ static void dev_alloc(const Problem& P, const Host& h, Dev& d) {
     HIP_CHECK(hipMemset(d.dv, 0xff, nk * 2));
 }
 static void dev_free(Dev& d) {
-    void* ps[] = {d.q, d.k, d.v, d.o, d.dout, d.dq, d.dk, d.dv, d.mask, d.bias, d.lse, d.delta};
+    void* ps[] = {d.q, d.k, d.v, d.o, d.dout, d.dq, d.dk, d.dv, d.mask, d.bias, d.lse, d.delta, d.ws};
     for (void* p : ps)
         if (p) (void)hipFree(p);
 }
@@ -239,7 +241,8 @@ static fasn_view4 view(void* p, int H, int S, int D) {
     v.stride[3] = 1;
     return v;
 }
-static void fill_args(const Problem& P, const Host& h, const Dev& d, fasn_bwd_args& a) {
+static int g_one_pass = 0;   // harness switch: request the one-pass backward (`test ... onepass`, bench bwd_variant bit 3)
+static void fill_args(const Problem& P, const Host& h, Dev& d, fasn_bwd_args& a) {
     memset(&a, 0, sizeof(a));
     fasn_fwd_args& f = a.fwd;
     f.q = view(d.q, P.H, P.Sq, P.D);
@@ -266,6 +269,16 @@ static void fill_args(const Problem& P, const Host& h, const Dev& d, fasn_bwd_ar
     a.dk = view(d.dk, P.H, P.Sk, P.D);
     a.dv = view(d.dv, P.H, P.Sk, P.D);
     a.delta = d.delta;
+    // one-pass backward (opt-in; g_one_pass): the fp32 dQ accumulator is the caller's (poisoned here: the library must clear it itself)
+    a.flags = g_one_pass ? FASN_BWD_ONE_PASS : 0;
+    const size_t wb = fasn_bwd_workspace_bytes(&a);
+    if (wb && d.ws == nullptr) {
+        HIP_CHECK(hipMalloc(&d.ws, wb));
+        HIP_CHECK(hipMemset(d.ws, 0xff, wb));
+        d.ws_bytes = wb;
+    }
+    a.workspace = d.ws;
+    a.workspace_bytes = d.ws_bytes;
 }
 
 static double cmp16(const std::vector<uint16_t>& got, size_t off, const std::vector<double>& ref, int dtype, double& refmax, int& nbad) {
@@ -440,6 +453,9 @@ static int do_test(int variant, bool quick) {
         {"d128 bf16 alibi+keypad n.5", mk(2, 4, 320, 320, 128, BF, 0, 0.5f, 1, 1), true},
         {"d64 f16 f32bias+mask causal n1", mk(1, 2, 130, 190, 64, HF, 1, 1.f, 2, 2), true},
         {"d64 bf16 scale.3 n4", mk(1, 1, 1024, 1152, 64, BF, 0, 4.f, 0, 0, 0.3f), true},
+        {"d64 bf16 1100x1300 causal n1", mk(1, 2, 1100, 1300, 64, BF, 1, 1.f), true},
+        {"d64 f16 1300x1100 causal n0", mk(1, 2, 1300, 1100, 64, HF, 1, 0.f), true},
+        {"d64 f16 33x1000 n1", mk(2, 2, 33, 1000, 64, HF, 0, 1.f), true},
     };
     if (!quick) {
         cases.push_back({"d64 bf16 (8,16,1024) n1", mk(8, 16, 1024, 1024, 64, BF, 0, 1.f), true});
@@ -471,7 +487,10 @@ static int do_bench(int argc, char** argv) {
     if (argc > 12) P.n = (float)atof(argv[12]);
     if (argc > 13) P.mask_kind = atoi(argv[13]);
     if (argc > 14) P.bias_kind = atoi(argv[14]);
-    if (argc > 15) fasn_dev_set_bwd_variant(atoi(argv[15]));
+    if (argc > 15) {   // bit 3 (8): request the one-pass backward
+        fasn_dev_set_bwd_variant(atoi(argv[15]));
+        g_one_pass = (atoi(argv[15]) >> 3) & 1;
+    }
     Host h;
     make_inputs(P, h, 3);
     Dev d;
@@ -520,7 +539,10 @@ int main(int argc, char** argv) {
     }
     std::string cmd = argv[1];
     if (cmd == "probe") return do_probe();
-    if (cmd == "test") return do_test(argc > 2 ? atoi(argv[2]) : 0, argc > 3 && atoi(argv[3]) != 0);
+    if (cmd == "test") {
+        g_one_pass = argc > 4 && atoi(argv[4]) != 0;   // test [variant] [quick] [one_pass]
+        return do_test(argc > 2 ? atoi(argv[2]) : 0, argc > 3 && atoi(argv[3]) != 0);
+    }
     if (cmd == "bench") return do_bench(argc, argv);
     return 2;
 }
