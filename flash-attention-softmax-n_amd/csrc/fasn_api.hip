@@ -191,12 +191,13 @@ int dispatch_fwd(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 
 namespace {
 __global__ void rng_advance_kernel(uint64_t* state, uint64_t* out, uint64_t increment) {
-    const uint64_t s = state[0], o = state[1];
+    // fetch-add: two streams of one device advancing the same stream position concurrently never draw the same offset
+    const uint64_t s = state[0];
+    const uint64_t o = atomicAdd(reinterpret_cast<unsigned long long*>(state + 1), (unsigned long long)increment);
     if (out != nullptr) {
         out[0] = s;
         out[1] = o;
     }
-    state[1] = o + increment;
 }
 }  // namespace
 

@@ -54,34 +54,37 @@ def _stream_ptr(device) -> int:
 
 
 # ---- dropout stream (reference: torch's philox generator behind core/flash_attn.py:122 and core/functional.py:92) ----
-# One {seed, offset} pair per device lives IN DEVICE MEMORY. Every dropout call takes its own copy of the pair and advances the
-# offset with one tiny kernel on the launch stream (fasn_rng_advance): no host synchronisation, and a captured HIP graph that
-# contains the call draws a fresh mask on every replay. The pair is (re)initialised from torch's CUDA generator of the device
-# - seed = its initial_seed(), offset = its philox offset - whenever that generator was re-seeded (torch.manual_seed), so
-# seeded runs are reproducible; the generator's own offset is advanced as well, as any torch random op would.
+# Eager calls: a call's (seed, offset) is a PURE FUNCTION of torch's CUDA generator of the device at call time - seed =
+# initial_seed(), offset = its philox offset, which the call then advances by 4 as any torch random op would - and travels by
+# value. torch.manual_seed reproduces a run, and whatever saves / restores the generator state (torch.utils.checkpoint,
+# HF gradient_checkpointing) makes the recomputed forward draw the mask of the original one.
+# Under HIP-graph capture nothing on the host runs at replay time, so captured calls draw from a {seed, offset} pair in DEVICE
+# memory instead: one tiny captured kernel (fasn_rng_advance) hands the call its copy and advances the pair, so every replay
+# resamples. The pair is created by the first eager dropout call after the generator was (re)seeded, with bit 62 of the offset
+# set: the graph stream and the eager stream of one seed never share a position.
 _RNG_STATE = {}
+_GRAPH_STREAM_BIT = 1 << 62
 
 
-def _next_rng_state(device) -> Tensor:
-    """int64[2] device tensor {seed, offset} for ONE forward call (its backward reads the same tensor)."""
-    lib = _lib.load()
+def _next_rng_state(device):
+    """(seed, offset) Python ints for one eager forward call, or - while the current stream is capturing - an int64[2] device
+    tensor {seed, offset} filled by a captured kernel. The backward of the call gets the same object."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    capturing = torch.cuda.is_current_stream_capturing()
     st = _RNG_STATE.get(idx)
-    if not capturing:
+    if not torch.cuda.is_current_stream_capturing():
         gen = torch.cuda.default_generators[idx]
         seed, off = gen.initial_seed(), gen.get_offset()
-        if st is None or st["seed"] != seed or off < st["torch_offset"]:   # first use, or the generator was re-seeded
-            state = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, off], dtype=torch.int64, device=device)
-            st = _RNG_STATE[idx] = {"seed": seed, "state": state, "torch_offset": off}
         gen.set_offset(off + 4)
-        st["torch_offset"] = off + 4
-    elif st is None:
+        if st is None or st["seed"] != seed:   # first use, or the generator was re-seeded: (re)create the graph stream
+            signed = seed - (1 << 64) if seed >= (1 << 63) else seed
+            _RNG_STATE[idx] = {"seed": seed, "state": torch.tensor([signed, _GRAPH_STREAM_BIT + off], dtype=torch.int64, device=device)}
+        return seed & 0xFFFFFFFFFFFFFFFF, off & 0xFFFFFFFFFFFFFFFF
+    if st is None:
         raise RuntimeError("dropout inside a HIP graph capture: run one dropout call on this device before capturing "
                            "(the device-side random state is created on first use)")
     out = torch.empty(2, dtype=torch.int64, device=device)
     with torch.cuda.device(device):
-        _lib.check(lib.fasn_rng_advance(st["state"].data_ptr(), out.data_ptr(), 1, _stream_ptr(device)), "fasn_rng_advance")
+        _lib.check(_lib.load().fasn_rng_advance(st["state"].data_ptr(), out.data_ptr(), 1, _stream_ptr(device)), "fasn_rng_advance")
     return out
 
 
@@ -103,9 +106,12 @@ def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal, dropout
     a.softmax_n = n
     a.causal = 1 if causal else 0
     a.dropout_p = dropout_p
-    a.seed = seed
-    a.offset = offset
-    a.rng_state = None if rng is None else rng.data_ptr()
+    if isinstance(rng, tuple):     # eager call: this call's (seed, offset) by value
+        a.seed, a.offset = rng
+        a.rng_state = None
+    else:                          # captured call: device {seed, offset} (or no dropout)
+        a.seed, a.offset = seed, offset
+        a.rng_state = None if rng is None else rng.data_ptr()
 
 
 _BACKWARD_PLAN = "split"
@@ -127,7 +133,7 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
     """autograd glue; same role as _FlashAttentionN (flash_attn_triton.py:241-336)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, bias, n: float, scale: float, causal: bool, dropout_p: float = 0.0, rng: Optional[Tensor] = None):
+    def forward(ctx, q, k, v, mask, bias, n: float, scale: float, causal: bool, dropout_p: float = 0.0, rng=None):
         lib = _lib.load()
         B, H, L, D = q.shape
         o = torch.empty((B, H, L, v.shape[3]), dtype=q.dtype, device=q.device)
@@ -250,7 +256,7 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
             bias = bias.to(query.dtype)
         bias = bias.expand(B, H, L, S)
 
-    # dropout: this call's {seed, offset} in device memory (see _next_rng_state); the kernels derive every keep/drop bit from
+    # dropout: this call's (seed, offset) (see _next_rng_state); the kernels derive every keep/drop bit from
     # (seed, offset, b, h, row, key) - dropout.py is the host mirror
     rng = _next_rng_state(query.device) if dropout_p > 0.0 else None
     _attention.last_rng_state = rng
@@ -279,6 +285,8 @@ def last_dropout_state():
     t = getattr(_attention, "last_rng_state", None)
     if t is None:
         return None
+    if isinstance(t, tuple):
+        return t
     s, o = (int(x) for x in t.cpu().tolist())
     return s & 0xFFFFFFFFFFFFFFFF, o & 0xFFFFFFFFFFFFFFFF
 

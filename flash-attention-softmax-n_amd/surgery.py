@@ -138,22 +138,32 @@ def _hf_attention(module: Module, query: torch.Tensor, key: torch.Tensor, value:
         else:
             bias = attention_mask[..., : key.shape[-2]]
             keymask = _as_key_padding_mask(bias)
-            if keymask is not None:      # 0 / "minus infinity" padding mask: the kernels' key-padding path (no bias traffic)
-                mask, bias = keymask, None
+            if keymask is not None:
+                # row-broadcast additive mask: its hidden keys as the kernels' key-padding mask (padded tiles skipped). HF builds
+                # these as 0 / finfo.min from a binary mask, so the visible entries add nothing and the bias is dropped - unless
+                # ADDITIVE_KEY_MASKS_MAY_BE_SOFT says a caller feeds non-binary masks: then the finite entries stay a [B,1,1,S] bias
+                mask = keymask
+                bias = torch.where(keymask, bias[..., :1, :], torch.zeros((), dtype=bias.dtype, device=bias.device)) if ADDITIVE_KEY_MASKS_MAY_BE_SOFT else None
     out = flash_attention_n(query, key, value, softmax_n_param=n, scale=scaling, dropout_p=dropout if module.training else 0.0,
                             attn_mask=mask, attn_bias=bias, is_causal=bool(kwargs.get("is_causal", False)) and query.shape[2] > 1)
     return out.transpose(1, 2).contiguous(), None
 
 
+# transformers' extended attention mask is (1 - mask) * finfo.min: 0 / min for the binary masks tokenizers produce. A float mask
+# with values strictly between 0 and 1 ("soft" masking) gives finite non-zero additive entries; set this to True to keep them as
+# an additive key bias next to the key-padding mask (the bias + key-padding kernels instead of the plain key-padding ones).
+ADDITIVE_KEY_MASKS_MAY_BE_SOFT = False
+
+
 def _as_key_padding_mask(additive: torch.Tensor) -> Optional[torch.Tensor]:
     """Older `transformers` versions (and direct callers) hand every layer an ADDITIVE mask, [B,1,1,S] (or a row-broadcast
-    expansion of it) with 0 for real tokens and a huge negative number for padding. A row-broadcast additive mask is turned
-    into the boolean key mask `additive > -1e4` WITHOUT inspecting its values (no device synchronisation, nothing cached -
+    expansion of it) with 0 for real tokens and a huge negative number for padding. A row-broadcast additive mask yields the
+    boolean key mask `additive > -1e4` WITHOUT inspecting its values on the host (no device synchronisation, nothing cached -
     a cache keyed on the tensor's address would return a previous batch's mask once the allocator reuses the address):
-    entries above the threshold attend, entries at or below it (finfo.min, -inf, -1e9, -1e4) are hidden. A row-broadcast
-    mask whose finite entries are not 0 is not a padding mask; it keeps its additive meaning because the caller only takes
-    this route for masks that `_hf_mask` / HF's `get_extended_attention_mask` build, which are 0 / min by construction.
-    Anything with a real row dimension (e.g. causal) returns None and stays an additive bias."""
+    entries at or below the threshold (finfo.min, -inf, -1e9, -1e4) are hidden keys - the kernels skip their tiles.
+    The VALUES above the threshold are not looked at here: `_hf_attention` drops them (0 by HF's construction) unless
+    ADDITIVE_KEY_MASKS_MAY_BE_SOFT is set, in which case it keeps them as an additive key bias next to this mask.
+    Anything with a real row dimension (e.g. causal) returns None and stays an additive bias only."""
     if additive.dim() != 4 or additive.shape[1] != 1:
         return None
     if additive.shape[-2] != 1:
@@ -163,22 +173,37 @@ def _as_key_padding_mask(additive: torch.Tensor) -> Optional[torch.Tensor]:
     return additive > -1e4
 
 
-def _hf_mask(batch_size: int, q_length: int, kv_length: int, q_offset: int = 0, kv_offset: int = 0, mask_function=None,
-             attention_mask: Optional[torch.Tensor] = None, **kwargs):
+def _hf_mask(batch_size: int, cache_position: Optional[torch.Tensor] = None, kv_length: Optional[int] = None, kv_offset: int = 0,
+             mask_function=None, attention_mask: Optional[torch.Tensor] = None, q_length: Optional[int] = None, q_offset: int = 0,
+             **kwargs):
     """`transformers.AttentionMaskInterface` function for HF_ATTENTION_NAME. Without a registered mask function transformers
     hands a custom attention function `attention_mask=None` - every layer would silently attend to padding tokens.
+    Both calling conventions are served: transformers 4.53 - 4.5x pass `cache_position` (the query positions), newer versions
+    `q_length` / `q_offset`; whatever was received is forwarded to transformers' own `sdpa_mask`.
     Bidirectional models with a 2-D padding mask get it back as a boolean [B,1,L,S] view with ROW STRIDE 0 (True = attend),
     which is exactly the kernels' key-padding form (one byte per key, padded tiles skipped); everything else (causal,
     sliding window, packed sequences, or/and-mask functions) is built by transformers' own boolean `sdpa_mask`."""
+    import inspect
     from transformers import masking_utils as mu
-    if (attention_mask is not None and attention_mask.dim() == 2 and mask_function is getattr(mu, "bidirectional_mask_function", object())
+    if q_length is None and cache_position is not None:
+        q_length = int(cache_position.shape[0])
+    if (attention_mask is not None and attention_mask.dim() == 2 and kv_length is not None and q_length is not None
+            and mask_function is getattr(mu, "bidirectional_mask_function", object())
             and attention_mask.shape[-1] >= kv_offset + kv_length):
         keys = attention_mask[:, kv_offset:kv_offset + kv_length].to(torch.bool)
         return keys[:, None, None, :].expand(batch_size, 1, q_length, kv_length)
     kwargs.pop("allow_is_bidirectional_skip", None)
     # never "skip" to None for a padded batch; an all-True mask may still come back as None, which means "no mask"
-    return mu.sdpa_mask(batch_size=batch_size, q_length=q_length, kv_length=kv_length, q_offset=q_offset, kv_offset=kv_offset,
-                        mask_function=mask_function, attention_mask=attention_mask, **kwargs)
+    have = dict(batch_size=batch_size, cache_position=cache_position, kv_length=kv_length, kv_offset=kv_offset,
+                mask_function=mask_function, attention_mask=attention_mask, q_length=q_length, q_offset=q_offset, **kwargs)
+    params = inspect.signature(mu.sdpa_mask).parameters
+    if not any(prm.kind is inspect.Parameter.VAR_KEYWORD for prm in params.values()):
+        have = {k_: v_ for k_, v_ in have.items() if k_ in params}   # this version's sdpa_mask takes only what it names
+    elif "cache_position" not in params:
+        have.pop("cache_position", None)
+    if mask_function is None:
+        have.pop("mask_function", None)   # sdpa_mask's own default (causal)
+    return mu.sdpa_mask(**have)
 
 
 def register_hf_attention() -> bool:

@@ -605,9 +605,9 @@ def test_dropout_reference_grid_is_finite_and_unbiased(pkg, dev):
 
 
 def test_dropout_stream_follows_the_torch_generator_and_resamples_in_graph_replays(pkg, dev):
-    """The (seed, offset) of a call comes from a per-device stream in DEVICE memory seeded by torch's CUDA generator
-    (reference: torch's philox state behind core/flash_attn.py:122): re-seeding reproduces the sequence, consecutive calls differ,
-    and a captured forward + backward draws a fresh mask on every replay - each replay still matching the host mirror."""
+    """An eager call's (seed, offset) is the state of torch's CUDA generator at call time (reference: torch's philox state behind
+    core/flash_attn.py:122): re-seeding reproduces the sequence, consecutive calls differ; a captured forward + backward draws from
+    the device-resident graph stream and resamples on every replay - each replay still matching the host mirror."""
     dtype = torch.bfloat16
     B, H, L, S, D, p = 2, 2, 128, 192, 64, 0.1
     q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
@@ -617,7 +617,7 @@ def test_dropout_stream_follows_the_torch_generator_and_resamples_in_graph_repla
     s1 = pkg.flash_attn.last_dropout_state()
     a2 = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, dropout_p=p)
     s2 = pkg.flash_attn.last_dropout_state()
-    assert s1[0] == 99 and s2[0] == 99 and s2[1] == s1[1] + 1 and not torch.equal(a1, a2)
+    assert s1[0] == 99 and s2[0] == 99 and s2[1] == s1[1] + 4 and not torch.equal(a1, a2)   # torch's generator advanced by 4 per call
     torch.manual_seed(99)
     b1 = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, dropout_p=p)
     assert pkg.flash_attn.last_dropout_state() == s1 and torch.equal(a1, b1)
@@ -647,12 +647,43 @@ def test_dropout_stream_follows_the_torch_generator_and_resamples_in_graph_repla
         outs.append((go.detach().clone(), sq.grad.detach().clone(), sk.grad.detach().clone(), sv.grad.detach().clone()))
         states.append(tuple(int(x) & 0xFFFFFFFFFFFFFFFF for x in state_t.cpu().tolist()))
     assert states[1][1] == states[0][1] + 1 and states[2][1] == states[1][1] + 1      # the offset advances on the device
+    assert states[0][1] >> 62 == 1                                                     # graph stream: disjoint from the eager one
     assert not torch.equal(outs[0][0], outs[1][0]) and not torch.equal(outs[1][0], outs[2][0])
     for (o_, dq_, dk_, dv_), (seed, offset) in zip(outs, states):
         keep = pkg.dropout.keep_mask(seed, offset, B, H, L, S, p)
         o, dq, dk, dv = _oracle_dropout(q, k, v, do, keep, pkg.dropout.effective_p(p), softmax_n_param=1.0)
         for got, want, nm in ((o_, o, "out"), (dq_, dq, "dq"), (dk_, dk, "dk"), (dv_, dv, "dv")):
             _check(got, want, dtype, f"graph replay/{nm}")
+
+
+@pytest.mark.parametrize("reentrant", [False, True])
+def test_dropout_under_activation_checkpointing(pkg, dev, reentrant):
+    """torch.utils.checkpoint restores the CUDA generator state before it recomputes a block: the recomputed forward (and the
+    backward that follows it) must draw the masks of the original forward. Two attention layers with dropout, each
+    checkpointed, against the same two layers run plainly from the same seed."""
+    from torch.utils.checkpoint import checkpoint
+    dtype, p = torch.bfloat16, 0.2
+    B, H, L, D = 2, 2, 256, 64
+    x0 = _rand((B, H, L, D), dtype, dev, 5)
+    w = [(_rand((D, D), dtype, dev, 20 + i, std=0.2)) for i in range(4)]
+
+    def layer(x, wq, wk):
+        return x + pkg.flash_attention_n(x @ wq, x @ wk, x, softmax_n_param=1.0, dropout_p=p, is_causal=True)
+
+    def run(use_ckpt):
+        torch.manual_seed(1234)
+        x = x0.clone().requires_grad_()
+        ws = [t.clone().requires_grad_() for t in w]
+        pkg.flash_attention_n(x0, x0, x0, dropout_p=p)   # a call before the layers: the generator is not at its initial offset
+        h = x
+        for i in range(2):
+            h = checkpoint(layer, h, ws[2 * i], ws[2 * i + 1], use_reentrant=reentrant) if use_ckpt else layer(h, ws[2 * i], ws[2 * i + 1])
+        h.float().square().sum().backward()
+        return [h.detach()] + [t.grad for t in [x] + ws]
+
+    plain, ckpt = run(False), run(True)
+    for a, b_ in zip(plain, ckpt):
+        assert torch.equal(a, b_)
 
 
 # ---------------------------------------------------------------- size-independent properties at full BASELINE sizes

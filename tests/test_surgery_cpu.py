@@ -207,3 +207,26 @@ def test_additive_padding_masks_are_converted_without_a_cache():
     assert counts == [60, 70, 50, 64, 33]
     assert surgery._as_key_padding_mask(torch.zeros(2, 1, 16, 80)) is None      # a real row dimension: stays a bias
     assert surgery._as_key_padding_mask(torch.zeros(2, 4, 1, 80)) is None       # per-head: not HF's padding mask
+
+
+def test_hf_mask_serves_both_transformers_calling_conventions():
+    """transformers 4.53 - 4.5x call a registered mask function with `cache_position` (no q_length / q_offset), newer versions with
+    q_length / q_offset: both must give the boolean [B,1,L,S] key-padding view (row stride 0) for a bidirectional padded batch and
+    otherwise reach transformers' own sdpa_mask without a TypeError."""
+    mu = pytest.importorskip("transformers.masking_utils")
+    bidir = getattr(mu, "bidirectional_mask_function", None)
+    am = torch.ones(2, 12, dtype=torch.long)
+    am[1, 9:] = 0
+    if bidir is not None:
+        new = surgery._hf_mask(batch_size=2, q_length=12, kv_length=12, q_offset=0, kv_offset=0, mask_function=bidir, attention_mask=am)
+        old = surgery._hf_mask(batch_size=2, cache_position=torch.arange(12), kv_length=12, kv_offset=0, mask_function=bidir, attention_mask=am)
+        for m in (new, old):
+            assert m.dtype == torch.bool and tuple(m.shape) == (2, 1, 12, 12) and m.stride(2) == 0
+            assert m[1, 0, 0].tolist() == [True] * 9 + [False] * 3
+    # a causal request goes to sdpa_mask under either convention
+    for kw in (dict(q_length=6, q_offset=0), dict(cache_position=torch.arange(6))):
+        try:
+            m = surgery._hf_mask(batch_size=2, kv_length=6, kv_offset=0, mask_function=mu.causal_mask_function, attention_mask=am[:, :6], **kw)
+        except TypeError as e:   # only acceptable when THIS transformers version's sdpa_mask itself lacks the argument we could not derive
+            pytest.fail(f"_hf_mask raised {e}")
+        assert m is None or (m.dtype == torch.bool and m.shape[-2:] == (6, 6))
