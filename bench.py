@@ -2,7 +2,7 @@
 """bench.py — headline benchmark of the hot path (BASELINE.json): attn-ops/s of flash_attention_n at
 (B=8, H=16, S=4096, D=64) bf16, n=1, non-causal, on N replicated GPUs (no sharding, no RCCL on the data path).
 
-  python bench.py --gpus N --steps K --warmup W [--workload m0|c2|c3|c4|c5] [--pass fwd|bwd|fwdbwd]
+  python bench.py --gpus N --steps K --warmup W [--workload m0|c1|c2|c3|c4|c5] [--pass fwd|bwd|fwdbwd] [--backward-plan split|one_pass]
 
 N > 1: bench.py launches its own N replica processes (one per GPU, gloo control plane over 127.0.0.1) when it is started
 without WORLD_SIZE; started under `python -m torch.distributed.run --nproc-per-node N ...` it joins that world instead.
@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (B, H, S, D, dtype, n, causal)
+    "c1": (2, 2, 128, 32, "f32", 1.0, False),      # BASELINE config 1: the reference's CPU-runnable case (slow_attention_n fp32), timed IN FULL on the host
     "m0": (8, 16, 4096, 64, "bf16", 1.0, False),   # the shape BASELINE.json's metric is quoted on
     "c2": (8, 16, 1024, 64, "bf16", 1.0, False),
     "c3": (8, 16, 4096, 64, "f16", 1.0, True),
@@ -39,6 +40,7 @@ WORKLOADS = {
     "c4": (4, 32, 8192, 128, "bf16", 0.5, False),   # + dense ALiBi bias [H,L,S] and key-padding mask [B,1,1,S]
 }
 PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak, MI355X (MI355X_MICROARCH.md)
+PEAK_TFLOPS_F32 = 157.3   # fp32-input MFMA (v_mfma_f32_32x32x2_f32) = the fp32 vector rate, 1/16 of bf16 (same guide)
 # GEMM-equivalents (one = 2*B*H*Sq*Sk*D flops): forward 2 (QK^T, PV); backward 5 in the textbook algorithm (S, dP, dV, dK, dQ),
 # 7 executed by the deterministic two-kernel split (S and dP are recomputed by both the dQ and the dK/dV kernel)
 GEMMS = {"fwd": (2, 2), "bwd": (5, 7), "fwdbwd": (7, 9)}
@@ -48,10 +50,18 @@ def fwd_flops(B, H, S, D, causal):
     return 4.0 * B * H * D * (S * (S + 1) / 2 if causal else S * S)
 
 
-def pass_flops(which, B, H, S, D, causal):
-    """(algorithmic, executed) flops of one step of `which`"""
+def pass_flops(which, B, H, S, D, causal, visible_key_fraction=1.0):
+    """(algorithmic, executed) flops of one step of `which`. `visible_key_fraction` < 1: a key-padding mask whose fully padded
+    64-key tiles the kernels do not walk (C4) - the algorithmic count keeps SURVEY 8(d)'s definition (every score of the
+    [S x S] grid), the executed count follows the tiles that actually run (checked against SQ_INSTS_MFMA in profiles/)."""
     g = fwd_flops(B, H, S, D, causal) / 2.0
-    return GEMMS[which][0] * g, GEMMS[which][1] * g
+    return GEMMS[which][0] * g, GEMMS[which][1] * g * visible_key_fraction
+
+
+def visible_tile_fraction(B, S, tile=64):
+    """share of the (batch, 64-key tile) pairs that hold at least one visible key under synth.keypad_mask's lengths"""
+    fr = [1.0, 0.875, 0.75, 0.5]
+    return sum(-(-int(S * fr[b % 4]) // tile) for b in range(B)) * tile / float(B * S)
 
 
 def lib_sha256():
@@ -150,6 +160,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="m0", choices=sorted(WORKLOADS))
+    ap.add_argument("--backward-plan", default="split", choices=["split", "one_pass"],
+                    help="fasn_bwd plan: the deterministic dQ + dK/dV split (default) or the opt-in one-pass backward (D = 64, plain / causal)")
     ap.add_argument("--pass", dest="which", default="fwd", choices=["fwd", "bwd", "fwdbwd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-passes", action="store_true", help="default forward run: skip the backward / fwdbwd objects")
@@ -168,6 +180,8 @@ def main():
         sys.exit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a different GPU count than asked")
 
     B, H, S, D, dname, n, causal = WORKLOADS[args.workload]
+    vis = visible_tile_fraction(B, S) if args.workload == "c4" else 1.0
+    peak = PEAK_TFLOPS_F32 if dname == "f32" else PEAK_TFLOPS
     stub = args.stub_step_ms is not None
     ctl = Control(rank, world)
     extra = {}
@@ -184,11 +198,12 @@ def main():
             sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dname]
+        dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dname]
 
         import flash_attention_softmax_n_amd as pkg
         from flash_attention_softmax_n_amd import synth
         lib, fa = pkg._lib.load(), pkg.flash_attn
+        pkg.set_backward_plan(args.backward_plan)
         q, k, v = (synth.counter_normal((B, H, S, D), seed, dtype=dtype, device=dev) for seed in (101, 102, 103))
         do = synth.counter_normal((B, H, S, D), 104, std=1.0, dtype=dtype, device=dev)
         bias = mask = None
@@ -224,6 +239,11 @@ def main():
         fa._fill_fwd(bargs.fwd, q, k, v, o_s, lse, m8, b4, n, 1.0 / D ** 0.5, causal)
         bargs.dout, bargs.dq, bargs.dk, bargs.dv = (fa._view4(t) for t in (do, dq, dk, dv))
         bargs.delta = delta.data_ptr()
+        bargs.flags = pkg._lib.FASN_BWD_ONE_PASS if args.backward_plan == "one_pass" else 0
+        ws_bytes = lib.fasn_bwd_workspace_bytes(bargs)   # > 0: the one-pass plan applies; its fp32 dQ accumulator is the caller's
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            bargs.workspace, bargs.workspace_bytes = ws.data_ptr(), ws_bytes
 
         def step_bwd():
             pkg._lib.check(lib.fasn_bwd(bargs, stream), "fasn_bwd")
@@ -259,7 +279,7 @@ def main():
             for w in ("bwd", "fwdbwd"):
                 dtw = timed(ctl, steps_of[w], sync, args.steps, args.warmup)
                 kms = kernel_time(raw["bwd"], 60) if w == "bwd" else None
-                alg, exe = pass_flops(w, B, H, S, D, causal)
+                alg, exe = pass_flops(w, B, H, S, D, causal, vis)
                 extra["backward" if w == "bwd" else "fwdbwd"] = {
                     "steps_per_s": args.steps / dtw, "ms_per_step": dtw / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
                     "algorithmic_tflops": alg / (dtw / args.steps) / 1e12, "executed_tflops": exe / (dtw / args.steps) / 1e12,
@@ -271,7 +291,9 @@ def main():
         return
 
     ops_per_s = world * args.steps / dt
-    alg, exe = pass_flops(args.which, B, H, S, D, causal)
+    alg, exe = pass_flops(args.which, B, H, S, D, causal, vis)
+    if args.backward_plan == "one_pass" and args.which != "fwd" and D == 64 and args.workload != "c1":
+        exe = alg   # the one-pass backward executes the 5 GEMMs of the algorithm
     names = {"fwd": "forward", "bwd": "backward", "fwdbwd": "forward+backward"}
     line = {
         "metric": f"attn-ops/sec (flash_attention_n {names[args.which]})", "value": ops_per_s, "unit": "attn-ops/s",
@@ -288,12 +310,15 @@ def main():
     else:
         achieved = alg / (kernel_ms * 1e-3) / 1e12
         line["roofline"] = {
-            "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": pmc_traffic(args.workload, args.which), "kernel_ms": kernel_ms,
             "kernels": {"fwd": "fasn_fwd_kernel", "bwd": "fasn_bwd_delta + fasn_bwd_dq + fasn_bwd_dkdv", "fwdbwd": "fasn_fwd_kernel + the three backward kernels"}[args.which],
             "algorithmic_flops_per_launch": alg, "executed_flops_per_launch": exe,
             "gemm_equivalents": {"algorithmic": GEMMS[args.which][0], "executed": GEMMS[args.which][1]},
-            "frac_executed": exe / (kernel_ms * 1e-3) / 1e12 / PEAK_TFLOPS}
+            "frac_executed": exe / (kernel_ms * 1e-3) / 1e12 / peak,
+            **({"visible_key_tile_fraction": vis} if vis < 1.0 else {})}
+        if args.backward_plan == "one_pass" and args.which != "fwd":
+            line["roofline"]["kernels"] = "fasn_bwd_delta + fasn_bwd_fused + fasn_bwd_dq_convert (one-pass plan)"
         line.update(extra)
 
     if not stub and world == 1 and not args.no_cpu_baseline:
@@ -302,29 +327,36 @@ def main():
         import platform
         import torch
         from oracle.ref_attention import ref_attention_n
+        full = args.workload == "c1"          # BASELINE config 1 is timed in full: all of (2,2,128,32) fp32, many repeats
         hs = H if S <= 4096 else 2
-        qc, kc, vc = (t[0:1, :hs].cpu() for t in (q, k, v))
+        nb = B if full else 1
+        qc, kc, vc = (t[0:nb, :hs].cpu() for t in (q, k, v))
         threads = torch.get_num_threads()
         bc = None if bias is None else bias[:hs].cpu()
         mc = None if mask is None else mask[0:1].cpu()
+        reps = 200 if full else 1
+        ref = ref_attention_n(qc, kc, vc, softmax_n_param=n, is_causal=causal, attn_bias=bc, attn_mask=mc) if full else None   # warm-up
         t1 = time.perf_counter()
-        ref = ref_attention_n(qc, kc, vc, softmax_n_param=n, is_causal=causal, attn_bias=bc, attn_mask=mc)
-        cpu_dt = time.perf_counter() - t1
-        frac = hs / (B * H)
+        for _ in range(reps):
+            ref = ref_attention_n(qc, kc, vc, softmax_n_param=n, is_causal=causal, attn_bias=bc, attn_mask=mc)
+        cpu_dt = (time.perf_counter() - t1) / reps
+        frac = (nb * hs) / (B * H)
         cpu_model = platform.processor() or "unknown"
         try:
             cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         except Exception:
             pass
-        line["cpu_baseline"] = {"value": frac / cpu_dt, "unit": "attn-ops/s (forward)", "cores": threads, "kind": "port", "extrapolated": True,
+        line["cpu_baseline"] = {"value": frac / cpu_dt, "unit": "attn-ops/s (forward)", "cores": threads, "kind": "port", "extrapolated": not full,
                                 "cpu": cpu_model,
-                                "sample": f"EXTRAPOLATED: batch 0, heads 0..{hs - 1} of the same inputs ({hs}/{B * H} of one forward op) took {cpu_dt:.2f} s, "
-                                          f"scaled linearly x{B * H // hs}; oracle/ref_attention.py (eager {dname}, as slow_attention_n)"}
+                                "sample": (f"IN FULL: the whole (B={B},H={H},S={S},D={D}) {dname} forward, mean of {reps} runs = {cpu_dt * 1e3:.3f} ms; "
+                                           f"oracle/ref_attention.py (eager, as slow_attention_n)") if full else
+                                          (f"EXTRAPOLATED: batch 0, heads 0..{hs - 1} of the same inputs ({hs}/{B * H} of one forward op) took {cpu_dt:.2f} s, "
+                                           f"scaled linearly x{B * H // hs}; oracle/ref_attention.py (eager {dname}, as slow_attention_n)")}
         out = out_holder.get("o")
         if out is None:
             step_fwd()
             out = out_holder["o"]
-        line["max_abs_err"] = float((out[0:1, :hs].float().cpu() - ref.float()).abs().max())
+        line["max_abs_err"] = float((out[0:nb, :hs].float().cpu() - ref.float()).abs().max())
         ref32 = ref_attention_n(qc[:, :2].float(), kc[:, :2].float(), vc[:, :2].float(), softmax_n_param=n, is_causal=causal,
                                 attn_bias=None if bc is None else bc[:2].float(), attn_mask=mc)
         line["max_abs_err_vs_fp32_oracle"] = float((out[0:1, :2].float().cpu() - ref32).abs().max())

@@ -46,6 +46,8 @@ def _rows_ok(t: Tensor) -> bool:
 
 
 def _canon(t: Tensor) -> Tensor:
+    if t.is_contiguous() and t.data_ptr() % 16 == 0 and (t.shape[-1] * t.element_size()) % 16 == 0:
+        return t   # the common case, one C++ call instead of a stride walk
     return t if _rows_ok(t) else t.contiguous()
 
 
@@ -129,24 +131,105 @@ def set_backward_plan(plan: str) -> str:
     return prev
 
 
+# ---- host path: one planned ABI call per pass, argument blocks cached per call signature -------------------------------------
+# Filling a ctypes struct costs ~0.15 us per field and a fasn_*_workspace_bytes() round trip ~2 us; both depend only on shapes,
+# strides, dtype and the scalar arguments. They are computed once per distinct signature (per thread: the cached block is
+# mutated in place) and a call only rewrites the pointers (reference launch site: core/flash_attn_triton.py:278-291, which
+# likewise passes raw pointers + strides per call).
+import threading
+
+_TLS = threading.local()
+
+
+def _sig(t: Optional[Tensor]):
+    return None if t is None else (t.shape, t.stride(), t.dtype)
+
+
+def _cache():
+    c = getattr(_TLS, "cache", None)
+    if c is None:
+        c = _TLS.cache = {}
+    return c
+
+
+class _Plan:
+    __slots__ = ("fwd", "fwd_ws", "bwd", "bwd_ws")
+
+
+def _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p, one_pass):
+    key = (_sig(q), _sig(k), _sig(v), _sig(mask), _sig(bias), n, scale, causal, dropout_p, one_pass, q.device.index)
+    c = _cache()
+    pl = c.get(key)
+    if pl is None:
+        if len(c) > 256:
+            c.clear()
+        lib = _lib.load()
+        B, H, L, _ = q.shape
+        o = torch.empty((B, H, L, v.shape[3]), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+        pl = _Plan()
+        pl.fwd = FwdArgs()
+        _fill_fwd(pl.fwd, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p)
+        pl.bwd = BwdArgs()
+        _fill_fwd(pl.bwd.fwd, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p)
+        dk = torch.empty((B, k.shape[1], k.shape[2], k.shape[3]), dtype=q.dtype, device=q.device)   # contiguous outputs: only the strides matter here
+        pl.bwd.dout, pl.bwd.dq, pl.bwd.dk, pl.bwd.dv = _view4(o), _view4(o), _view4(dk), _view4(dk)
+        pl.bwd.flags = _lib.FASN_BWD_ONE_PASS if one_pass else 0
+        with torch.cuda.device(q.device):
+            pl.fwd_ws = lib.fasn_fwd_workspace_bytes(pl.fwd)     # > 0: short-query / long-key shape, keys split over workgroups
+            pl.bwd_ws = lib.fasn_bwd_workspace_bytes(pl.bwd)     # > 0: one-pass backward, the fp32 dQ accumulator is ours to provide
+        c[key] = pl
+    return pl
+
+
+def _set_rng(a: FwdArgs, rng):
+    if isinstance(rng, tuple):     # eager call: this call's (seed, offset) by value
+        a.seed, a.offset = rng
+        a.rng_state = None
+    else:                          # captured call: device {seed, offset} (or no dropout)
+        a.seed = a.offset = 0
+        a.rng_state = None if rng is None else rng.data_ptr()
+
+
+def _launch_fwd(q, k, v, mask, bias, n, scale, causal, dropout_p, rng):
+    lib = _lib.load()
+    B, H, L, _ = q.shape
+    o = torch.empty((B, H, L, v.shape[3]), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+    pl = _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p, _BACKWARD_PLAN == "one_pass")
+    a = pl.fwd
+    a.q.ptr, a.k.ptr, a.v.ptr, a.o.ptr, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+    if mask is not None:
+        a.mask.ptr = mask.data_ptr()
+    if bias is not None:
+        a.bias.ptr = bias.data_ptr()
+    if dropout_p > 0.0:
+        _set_rng(a, rng)
+    dev = q.device
+
+    def launch():
+        if pl.fwd_ws:
+            ws = torch.empty(pl.fwd_ws, dtype=torch.uint8, device=dev)
+            _lib.check(lib.fasn_fwd_ws(a, ws.data_ptr(), pl.fwd_ws, _stream_ptr(dev)), "fasn_fwd_ws")
+        else:
+            rc = lib.fasn_fwd(a, _stream_ptr(dev))
+            if rc:
+                _lib.check(rc, "fasn_fwd")
+
+    if torch.cuda.current_device() == dev.index:   # the usual case: no device-guard object on the plain path
+        launch()
+    else:
+        with torch.cuda.device(dev):
+            launch()
+    return o, lse
+
+
 class _FlashAttentionSoftmaxN(torch.autograd.Function):
     """autograd glue; same role as _FlashAttentionN (flash_attn_triton.py:241-336)."""
 
     @staticmethod
     def forward(ctx, q, k, v, mask, bias, n: float, scale: float, causal: bool, dropout_p: float = 0.0, rng=None):
-        lib = _lib.load()
-        B, H, L, D = q.shape
-        o = torch.empty((B, H, L, v.shape[3]), dtype=q.dtype, device=q.device)
-        lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
-        a = FwdArgs()
-        _fill_fwd(a, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p, 0, 0, rng)
-        with torch.cuda.device(q.device):
-            ws_bytes = lib.fasn_fwd_workspace_bytes(a)   # > 0: short-query / long-key shape, keys split over workgroups
-            if ws_bytes:
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
-                _lib.check(lib.fasn_fwd_ws(a, ws.data_ptr(), ws_bytes, _stream_ptr(q.device)), "fasn_fwd_ws")
-            else:
-                _lib.check(lib.fasn_fwd(a, _stream_ptr(q.device)), "fasn_fwd")
+        o, lse = _launch_fwd(q, k, v, mask, bias, n, scale, causal, dropout_p, rng)
         ctx.save_for_backward(q, k, v, o, lse, mask, bias)
         ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, ctx.rng = n, scale, causal, dropout_p, rng
         return o
@@ -158,33 +241,46 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         dout = _canon(dout)
         B, H, L, D = q.shape
         S = k.shape[2]
-        # K/V with a broadcast (stride-0) head dimension get per-head gradients that are summed below
-        dq = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
+        dev = q.device
+        dq = torch.empty((B, H, L, D), dtype=q.dtype, device=dev)
         Hkv = k.shape[1]   # grouped-query attention: each dK/dV workgroup sums the query heads of its K/V head in registers
-        dk = torch.empty((B, Hkv, S, D), dtype=q.dtype, device=q.device)
-        dv = torch.empty((B, Hkv, S, v.shape[3]), dtype=q.dtype, device=q.device)
-        delta = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
-        a = BwdArgs()
-        _fill_fwd(a.fwd, q, k, v, o, lse, mask, bias, ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, 0, 0, ctx.rng)
-        a.dout, a.dq, a.dk, a.dv = _view4(dout), _view4(dq), _view4(dk), _view4(dv)
-        a.delta = delta.data_ptr()
-        a.workspace = None
-        a.workspace_bytes = 0
+        dk = torch.empty((B, Hkv, S, D), dtype=q.dtype, device=dev)
+        dv = torch.empty((B, Hkv, S, v.shape[3]), dtype=q.dtype, device=dev)
+        delta = torch.empty((B, H, L), dtype=torch.float32, device=dev)
         # plan: split kernels (default, deterministic) or the opt-in one-pass backward (fp32 atomics for dQ; never under
         # torch.use_deterministic_algorithms(True)) - see set_backward_plan()
-        a.flags = _lib.FASN_BWD_ONE_PASS if (_BACKWARD_PLAN == "one_pass" and not torch.are_deterministic_algorithms_enabled()) else 0
+        one_pass = _BACKWARD_PLAN == "one_pass" and not torch.are_deterministic_algorithms_enabled()
+        pl = _plan_for(q, k, v, mask, bias, ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, one_pass)
+        a = pl.bwd
+        f = a.fwd
+        f.q.ptr, f.k.ptr, f.v.ptr, f.o.ptr, f.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+        if mask is not None:
+            f.mask.ptr = mask.data_ptr()
+        if bias is not None:
+            f.bias.ptr = bias.data_ptr()
+        if ctx.dropout_p > 0.0:
+            _set_rng(f, ctx.rng)
+        if dout.stride() == o.stride():
+            a.dout.ptr = dout.data_ptr()
+        else:
+            a.dout = _view4(dout)
+        a.dq.ptr, a.dk.ptr, a.dv.ptr, a.delta = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
+        a.workspace, a.workspace_bytes = None, 0
         # gradient of attn_bias: the kernel writes dS densely; autograd sums it over the dimensions the caller's bias broadcasts
         # (the expand / unsqueeze / dtype cast in _attention are ordinary autograd ops)
         dbias = None
         if bias is not None and ctx.needs_input_grad[4]:
-            dbias = torch.zeros((B, H, L, S), dtype=q.dtype, device=q.device)   # tiles the causal walk skips are never written
+            dbias = torch.zeros((B, H, L, S), dtype=q.dtype, device=dev)   # tiles the causal walk skips are never written
             a.dbias = _view4(dbias)
-        with torch.cuda.device(q.device):
-            ws_bytes = lib.fasn_bwd_workspace_bytes(a)   # > 0: one-pass backward, the fp32 dQ accumulator is ours to provide
-            if ws_bytes:
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
-                a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
-            _lib.check(lib.fasn_bwd(a, _stream_ptr(q.device)), "fasn_bwd")
+        else:
+            a.dbias.ptr = None
+        with torch.cuda.device(dev):
+            if pl.bwd_ws:
+                ws = torch.empty(pl.bwd_ws, dtype=torch.uint8, device=dev)
+                a.workspace, a.workspace_bytes = ws.data_ptr(), pl.bwd_ws
+            _lib.check(lib.fasn_bwd(a, _stream_ptr(dev)), "fasn_bwd")
+        if dout.stride() != o.stride():
+            a.dout = _view4(o)   # restore the cached block's default strides
         if dbias is not None and dbias.dtype != bias.dtype:
             dbias = dbias.to(bias.dtype)
         return dq, dk, dv, None, dbias, None, None, None, None, None
@@ -223,7 +319,9 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
     Hkv = key.shape[1]
     if Hkv not in (1, H) and (H % Hkv != 0 or value.shape[1] != Hkv):
         raise ValueError(f"key/value have {Hkv} heads: must be 1, {H}, or a divisor of {H} (grouped-query attention)")
-    if Hkv in (1, H):
+    if Hkv == H:
+        pass
+    elif Hkv == 1:
         key = key.expand(B, H, S, E)
         value = value.expand(B, H, S, Ev)
     else:   # grouped-query attention: query head h reads K/V head h // (H // Hkv), through the head stride (no copy)
@@ -238,7 +336,10 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
     dpad = next((d for d in _SUPPORTED_D if d >= max(E, Ev)), None)
     if dpad is None:
         raise NotImplementedError(f"head dim {max(E, Ev)} > 128 is not supported")
-    q, k, v = (_canon(_pad_feature(t, dpad)) for t in (query, key, value))
+    if E == dpad and Ev == dpad:
+        q, k, v = _canon(query), _canon(key), _canon(value)
+    else:
+        q, k, v = (_canon(_pad_feature(t, dpad)) for t in (query, key, value))
 
     if mask is not None:
         if mask.dim() != 4:
@@ -275,7 +376,10 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
             out = _FlashAttentionSoftmaxN.apply(q.view(B, Hkv, G, dpad), k, v, mask_g, bias_g, n, scale, False, 0.0, None)
             out = out.view(B, H, 1, dpad)
             return out if Ev == dpad else out[..., :Ev]
-    out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, rng)
+    if not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad or (bias is not None and bias.requires_grad))):
+        out = _launch_fwd(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, rng)[0]   # nothing to differentiate: no autograd node
+    else:
+        out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, rng)
     return out if Ev == dpad else out[..., :Ev]
 
 
