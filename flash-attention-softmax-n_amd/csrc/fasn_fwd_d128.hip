@@ -30,7 +30,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.mode >= MODE_GENERAL && l.mode != MODE_KEYPAD) return launch_gen<Tag>(p, l, s);   // key-padding masks ride the plain tuning points
 #ifdef FASN_DEV_VARIANTS
     if (l.variant == 1) return launch_fwd_mode<Tag, 128, 1, 1>(p, l.mode, s);
-    // A/B and ablations (tools/fasn_harness bench ... <variant>); ablation results are not attention outputs
+    // A/B tuning points (tools/fasn_harness bench ... <variant>)
     if (l.variant == 40) return launch_fwd_ring<Tag, 128, 1, 2>(p, l.mode, s);
     if (l.variant == 43) return launch_fwd_ring<Tag, 128, 1, 2, 2>(p, l.mode, s);
     if (l.variant == 13) return launch_fwd_cfg<Tag, 128, 1, 2, 8, 0>(p, l.mode, s);   // 8 waves share one K/V tile
@@ -44,27 +44,6 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.variant == 82) return launch_fwd_cfg<Tag, 128, 1, 2, 4, 0, 2>(p, l.mode, s);   // 4-wave kernels (small grids)
     if (l.variant == 83) return launch_fwd_cfg<Tag, 128, 1, 2, 4, 2, 2>(p, l.mode, s);
     if (l.variant == 84) return launch_fwd_cfg<Tag, 128, 1, 2, 4, 0, 0>(p, l.mode, s);   // = the small-grid default, for A/B
-    if (l.variant == 4) return launch_fwd_pipe_mode<Tag, 128, 1, 2>(p, l.mode, s);      // software-pipelined, compiler order
-    if (l.variant == 5) return launch_fwd_pipe_mode<Tag, 128, 1, 2, 1>(p, l.mode, s);   // + burst order
-    if (l.variant == 6) return launch_fwd_pipe_mode<Tag, 128, 1, 1>(p, l.mode, s);
-    if (l.variant == 50) return launch_fwd_split<Tag, 128, 1, 2>(p, l.mode, s);   // 32-key sub-tiles
-    if (l.variant == 51) return launch_fwd_split<Tag, 128, 1, 1>(p, l.mode, s);
-    if (l.variant == 62) return launch_fwd_pipe_mode<Tag, 128, 1, 1, 3>(p, l.mode, s);   // hand-ordered pipelined block, one wave per SIMD
-    if (l.variant == 64) return launch_fwd_pipe_mode<Tag, 128, 1, 1, 4>(p, l.mode, s);   //   ablation: no staging
-    if (l.variant == 65) return launch_fwd_pipe_mode<Tag, 128, 1, 1, 5>(p, l.mode, s);   //   ablation: no staging, no barrier
-    if (l.variant == 68) return launch_fwd_pipe_mode<Tag, 128, 1, 1, 6>(p, l.mode, s);   //   ablation: + no LDS fragment reads
-    if (l.variant == 31) return launch_fwd_abl8<Tag, 128, 1, 2, 1>(p, s);   // 8-wave ablations: no exp
-    if (l.variant == 33) return launch_fwd_abl8<Tag, 128, 1, 2, 3>(p, s);   //   no PV MFMAs
-    if (l.variant == 35) return launch_fwd_abl8<Tag, 128, 1, 2, 5>(p, s);   //   no LDS fragment reads
-    if (l.variant == 36) return launch_fwd_abl8<Tag, 128, 1, 2, 6>(p, s);   //   no staging, no barrier
-    if (l.variant == 37) return launch_fwd_abl8<Tag, 128, 1, 2, 7>(p, s);   //   5 + 6
-    if (l.variant == 38) return launch_fwd_abl8<Tag, 128, 1, 2, 8>(p, s);   //   barrier, no staging
-    if (l.variant == 39) return launch_fwd_abl8<Tag, 128, 1, 2, 9>(p, s);   //   staging, no barrier
-    if (l.variant == 21) return launch_fwd_abl<Tag, 128, 1, 2, 1>(p, s);
-    if (l.variant == 23) return launch_fwd_abl<Tag, 128, 1, 2, 3>(p, s);
-    if (l.variant == 25) return launch_fwd_abl<Tag, 128, 1, 2, 5>(p, s);
-    if (l.variant == 26) return launch_fwd_abl<Tag, 128, 1, 2, 6>(p, s);
-    if (l.variant == 27) return launch_fwd_abl<Tag, 128, 1, 2, 7>(p, s);
 #endif
     // auto: with enough work to give every CU two 256-row blocks, one 8-wave workgroup per CU (eight waves share each staged
     // K/V tile, tiles loaded two ahead in two register sets) beats two 4-wave workgroups: 1134 vs 1014 TFLOP/s at

@@ -1,6 +1,6 @@
-// D = 64 forward instantiations. libfasn.so compiles the production tuning points only; the A/B tuning points and the
-// ablations (whose results are NOT attention outputs) exist in FASN_DEV_VARIANTS builds (tools/libfasn_dev.so) and are
-// selected by tools/fasn_harness through fasn_fwd_variant - nothing in the shipped library can reach them.
+// D = 64 forward instantiations. libfasn.so compiles the production tuning points only; the other tuning points of the same
+// kernel (staging scheme, rows per wave, waves per workgroup) exist in FASN_DEV_VARIANTS builds (tools/libfasn_dev.so) for A/B
+// runs through tools/fasn_harness and fasn_fwd_variant - nothing in the shipped library can reach them.
 #include "fasn_launch.h"
 namespace fasn {
 template <typename Tag>
@@ -57,36 +57,9 @@ static int dev_variant(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 85: return launch_fwd_ring<Tag, 64, 2, 2, 2, 0, 2>(p, l.mode, s);   // + row sums by v_dot2c on the packed weights (= the production plain kernel)
         case 86: return launch_fwd_ring<Tag, 64, 1, 3, 2, 0, 2>(p, l.mode, s);
         case 87: return launch_fwd_ring<Tag, 64, 1, 2, 1, 0, 2>(p, l.mode, s);
-        case 50: return launch_fwd_split<Tag, 64, 2, 2>(p, l.mode, s);
-        case 51: return launch_fwd_split<Tag, 64, 1, 3>(p, l.mode, s);
-        case 52: return launch_fwd_split<Tag, 64, 1, 2>(p, l.mode, s);
-        case 5: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 1>(p, l.mode, s);
-        case 60: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 2>(p, l.mode, s);   // pipelined + explicit MFMA/VALU interleave
-        case 61: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 2>(p, l.mode, s);
-        case 62: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 3>(p, l.mode, s);   // hand-ordered block
-        case 63: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 3>(p, l.mode, s);
-        case 64: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 4>(p, l.mode, s);   // ablation: no staging
-        case 65: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 5>(p, l.mode, s);   // ablation: no staging, no barrier
-        case 68: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 6>(p, l.mode, s);   // ablation: + no LDS fragment reads
-        case 69: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 6>(p, l.mode, s);
-        case 66: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 4>(p, l.mode, s);
-        case 67: return launch_fwd_pipe_mode<Tag, 64, 1, 2, 5>(p, l.mode, s);
-        case 7: return launch_fwd_pipe_mode<Tag, 64, 2, 1, 1>(p, l.mode, s);
-        case 8: return launch_fwd_pipe_mode<Tag, 64, 1, 1, 1>(p, l.mode, s);
-        case 4: return launch_fwd_pipe_mode<Tag, 64, 1, 2>(p, l.mode, s); break;
-        case 6: return launch_fwd_pipe_mode<Tag, 64, 2, 1>(p, l.mode, s); break;
-        case 9: return launch_fwd_pp_mode<Tag, 64, 2>(p, l.mode, s); break;
         case 13: return launch_fwd_w8_mode<Tag, 64, 2, 2, 0>(p, l.mode, s); break;
         case 15: return launch_fwd_w8_mode<Tag, 64, 1, 4, 0>(p, l.mode, s); break;
         case 16: return launch_fwd_w8_mode<Tag, 64, 1, 4, 1>(p, l.mode, s); break;
-        // ---- ablations (plain mode only; results are NOT attention outputs)
-        case 21: return launch_fwd_abl<Tag, 64, 2, 2, 1>(p, s);
-        case 23: return launch_fwd_abl<Tag, 64, 2, 2, 3>(p, s);
-        case 25: return launch_fwd_abl<Tag, 64, 2, 2, 5>(p, s);
-        case 26: return launch_fwd_abl<Tag, 64, 2, 2, 6>(p, s);
-        case 28: return launch_fwd_abl<Tag, 64, 2, 2, 8>(p, s);
-        case 29: return launch_fwd_abl<Tag, 64, 2, 2, 9>(p, s);
-        case 20: return launch_fwd_abl<Tag, 64, 2, 2, 10>(p, s);
         default: break;
     }
     return launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);

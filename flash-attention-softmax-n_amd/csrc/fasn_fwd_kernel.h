@@ -119,9 +119,6 @@ FASN_DEV void kp_build_words(uint64_t* words, const uint8_t* mrow, int Sk, int n
     }
 }
 
-// ABL (developer ablation, never dispatched by the ABI): 1 = no exponentials (P := raw S), 2 = no QK^T MFMAs,
-// 3 = no PV MFMAs, 4 = neither MFMA group, 5 = no K/V LDS fragment reads, 6 = no staging and no barrier,
-// 7 = 5 + 6, 8 = barrier but no staging, 9 = staging but no barrier, 10 = staging always reads tile 0
 // DROP: attention-weight dropout compiled in (separate instantiations so the no-dropout kernels keep their registers).
 // RING: 1 = two staging register sets, K/V tiles are loaded TWO tiles ahead (the loop body is instantiated twice with the
 // sets swapped). One tile of lead is about 1.2 us at D=64, less than a first-touch HBM miss under load; in-order vmcnt
@@ -129,15 +126,15 @@ FASN_DEV void kp_build_words(uint64_t* words, const uint8_t* mrow, int Sk, int n
 // RING: 2 = no staging registers at all: `buffer_load_dwordx4 ... lds` moves each 16-byte chunk straight from HBM/L2 into
 // the LDS tile image (LDS address = wave base + 16*lane, so the swizzle is applied by choosing WHICH global chunk a lane
 // fetches), three LDS tile buffers, loads issued two tiles ahead, `s_waitcnt vmcnt` before the barrier that publishes a tile.
-template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int ABL = 0, int DROP = 0, int RING = 0, int SPLIT = 0, int SEED = 0>
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int DROP = 0, int RING = 0, int SPLIT = 0, int SEED = 0>
 __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
     static_assert(!SEED || MODE != MODE_GENERAL_SLOW, "seeded accumulators: not for the element-load kernels");
-    static_assert(!SPLIT || (RING != 1 && DROP == 0 && ABL == 0), "split-K: single-set or direct-to-LDS staging");
+    static_assert(!SPLIT || (RING != 1 && DROP == 0), "split-K: single-set or direct-to-LDS staging");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     constexpr bool PSUM = SEED >= 2 && !DROP;   // fast-path row sums from the packed weights
     constexpr bool UNR3 = RING == 2 && (D <= 64 || (FASN_UNR3_D128 && NW == 8 && !mode_is_vector(MODE) && !DROP));  // direct-to-LDS loop unrolled by its three buffers
-    constexpr bool UNR2 = RING == 0 && ABL == 0 && FASN_FWD_UNR2;   // single-set staging: loop unrolled by its two LDS buffers
+    constexpr bool UNR2 = RING == 0 && FASN_FWD_UNR2;   // single-set staging: loop unrolled by its two LDS buffers
     constexpr int NT = NW * 64;
     constexpr int BM = NW * QB * 32;
     constexpr int ROWB = D * 2;
@@ -275,9 +272,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         constexpr int S_ = RING == 1 ? decltype(SET)::value : 0;   // RING 0 / 2 pass their LDS buffer index here (one or no register set)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            // ABL 10: every staging load fetches tile 0 (same instructions, always an L2 hit): separates instruction cost from memory latency
-            stK[S_][i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i], (ABL == 10 ? 0 : t) * ktile_bytes, 0);
-            stV[S_][i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i], (ABL == 10 ? 0 : t) * vtile_bytes, 0);
+            stK[S_][i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[i], t * ktile_bytes, 0);
+            stV[S_][i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[i], t * vtile_bytes, 0);
         }
     };
     auto stage_store = [&](int buf, auto SET) {
@@ -470,11 +466,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         // buffer offset folds into the ds_read immediates and the DMA's M0 values instead of two VALU per LDS address
         // (D <= 64 and the plain 8-wave D = 128 kernel; the D = 128 mask / bias and 4-wave kernels measured 1-2 % slower with the
         // tripled loop body, instruction cache)
-        const int buf = (ABL == 6 || ABL == 7) ? 0 : ((UNR3 || UNR2) ? decltype(LSET)::value : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1))));
+        const int buf = (UNR3 || UNR2) ? decltype(LSET)::value : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1)));
         const int buf2 = UNR3 ? (decltype(LSET)::value + 2) % 3 : (t + 2) % 3;   // RING 2: buffer of the tile requested now
         const int k0 = t * KT;
         if (RING == 2 && !VEC) stage_direct(t + 2, buf2);   // past-the-end tiles are out of range for the descriptor
-        else if (!VEC && ABL != 6 && ABL != 7 && ABL != 8 && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
+        else if (!VEC && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
 
         uint64_t kp_bits = ~0ull;
         if (KP) {   // (the builtin returns a signed int)
@@ -530,18 +526,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
-                        vec8 kf;
-                        if (ABL == 5 || ABL == 7) { kf = qf[0][s]; asm volatile("" : "+v"(kf)); }
-                        else kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
+                        const vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
 #pragma unroll
-                        for (int qb = 0; qb < QB; ++qb) {
-                            if (ABL == 2 || ABL == 4) {
-                                asm volatile("" : "+v"(kf));
-                                sacc[qb][kb][s] += 1.0f;
-                            } else {
-                                sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
-                            }
-                        }
+                        for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
                     }
                 }
             };
@@ -648,9 +635,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                                     const int r = 8 * t2 + e;
                                     const f32x2 s2 = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
                                     const f32x2 t = SEED ? s2 : __builtin_elementwise_fma(s2, c2, m2);
-                                    f32x2 pv;
-                                    if (ABL == 1) pv = s2;
-                                    else pv = f32x2{fast_exp2(t[0]), fast_exp2(t[1])};
+                                    const f32x2 pv = {fast_exp2(t[0]), fast_exp2(t[1])};
                                     x[e] = pv[0];
                                     x[e + 1] = pv[1];
                                     if (!PSUM) rs2 += pv;
@@ -671,7 +656,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     using T_ = std::true_type;
                     using F_ = std::false_type;
                     fast(F_{});
-                    if (ABL == 0 && __any(!(rs <= kSumLimit))) exact = true;
+                    if (__any(!(rs <= kSumLimit))) exact = true;
                     else l_run[qb] += rs;
                 }
                 if (exact) {
@@ -789,18 +774,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                     for (int d = 0; d < DB; ++d) {
-                        vec8 vf;
-                        if (ABL == 5 || ABL == 7) { vf = qf[0][d]; asm volatile("" : "+v"(vf)); }
-                        else vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, d, lane);
+                        const vec8 vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, d, lane);
 #pragma unroll
-                        for (int qb = 0; qb < QB; ++qb) {
-                            if (ABL == 3 || ABL == 4) {
-                                asm volatile("" : "+v"(vf), "+v"(pf[qb][kb][t2]));
-                                oacc[qb][d][kb * 2 + t2] += 1.0f;
-                            } else {
-                                oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
-                            }
-                        }
+                        for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
                     }
         }
 
@@ -811,9 +787,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 gen_dma(t + 2);
             }
             __syncthreads();
-        } else if (ABL != 6 && ABL != 7) {
-            if (ABL != 8 && (VEC || RING || t + 1 < ntiles)) stage_store(buf ^ 1, SSET);
-            if (ABL != 9) __syncthreads();   // ABL 8: barrier only; ABL 9: staging only
+        } else {
+            if (VEC || RING || t + 1 < ntiles) stage_store(buf ^ 1, SSET);
+            __syncthreads();
         }
     };
     if (RING == 1) {

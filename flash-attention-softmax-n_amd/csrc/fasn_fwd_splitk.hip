@@ -13,7 +13,7 @@ int launch_splitk_one(FwdParams p, hipStream_t s) {
     constexpr int OCC = 2;
     constexpr int smem = fwd_smem(D, RING, MODE, 4, 1);
     p.nqblk = (p.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_fwd_kernel<Tag, D, 1, MODE, OCC, 4, 0, 0, 0, RING, 1>;
+    constexpr auto kern = &fasn_fwd_kernel<Tag, D, 1, MODE, OCC, 4, 0, 0, RING, 1>;
     ensure_smem<kern>(smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.nsplit * p.B * p.H)), dim3(256), smem, s, p);
     const int64_t nthr = (int64_t)p.B * p.H * p.Sq * (D / 4);

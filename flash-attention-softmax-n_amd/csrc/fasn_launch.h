@@ -1,16 +1,11 @@
 // fasn_launch.h — host-side launch plumbing shared by the per-head-dim translation units.
-// The production launchers come first; everything under FASN_DEV_VARIANTS (A/B tuning points, ablation kernels whose
-// results are not attention outputs) is compiled only into the developer library tools/libfasn_dev.so that
-// tools/fasn_harness links — libfasn.so carries none of it and has no way to select it.
+// The production launchers come first; everything under FASN_DEV_VARIANTS (A/B tuning points of the same kernels) is compiled
+// only into the developer library tools/libfasn_dev.so that tools/fasn_harness links — libfasn.so carries none of it and has
+// no way to select it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include "fasn_fwd_kernel.h"
-#ifdef FASN_DEV_VARIANTS
-#include "fasn_fwd_pipe.h"
-#include "fasn_fwd_pp.h"
-#include "fasn_fwd_split.h"
-#endif
 
 namespace fasn {
 
@@ -53,7 +48,7 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
     constexpr int BM = NW * QB * 32;
     constexpr int smem = fwd_smem(D, RING, MODE, NW, QB);
     p.nqblk = (p.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, 0, 0, DROP, RING, 0, SEED>;
+    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, 0, DROP, RING, 0, SEED>;
     ensure_smem<kern>(smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(NW * 64), smem, s, p);
     return launch_rc();
@@ -106,43 +101,13 @@ int launch_fwd_mode(const FwdParams& p, int mode, hipStream_t s) {   // unseeded
     return launch_fwd_cfg<Tag, D, QB, OCC, 4, 0, 0>(p, mode, s);
 }
 
-template <typename Tag, int D, int QB, int MODE, int OCC, int BURST = 0>
-int launch_fwd_pipe_one(FwdParams p, hipStream_t s) {
-    constexpr int BM = 4 * QB * 32;
-    constexpr int smem = 4 * KT * D * 2;
-    p.nqblk = (p.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_fwd_pipe_kernel<Tag, D, QB, MODE, OCC, BURST>;
-    ensure_smem<kern>(smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
-    return launch_rc();
-}
-template <typename Tag, int D, int QB, int OCC, int BURST = 0>
-int launch_fwd_pipe_mode(const FwdParams& p, int mode, hipStream_t s) {
-    if (mode == MODE_PLAIN) return launch_fwd_pipe_one<Tag, D, QB, MODE_PLAIN, OCC, BURST>(p, s);
-    return launch_fwd_pipe_one<Tag, D, QB, MODE_CAUSAL, OCC, BURST>(p, s);
-}
-
-// ablation launcher (plain mode): results are NOT attention outputs
-template <typename Tag, int D, int QB, int OCC, int ABL, int NW = 4>
-int launch_fwd_abl(FwdParams p, hipStream_t s) {
-    constexpr int BM = NW * QB * 32;
-    constexpr int smem = 4 * KT * D * 2;
-    p.nqblk = (p.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE_PLAIN, OCC, NW, 0, ABL>;
-    ensure_smem<kern>(smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(NW * 64), smem, s, p);
-    return launch_rc();
-}
-template <typename Tag, int D, int QB, int OCC, int ABL>
-int launch_fwd_abl8(const FwdParams& p, hipStream_t s) { return launch_fwd_abl<Tag, D, QB, OCC, ABL, 8>(p, s); }
-
 // two staging register sets / direct-to-LDS with a static wave priority
 template <typename Tag, int D, int QB, int MODE, int OCC, int RING = 1, int PRIO = 0, int SEED = 0, int NW = 4>
 int launch_fwd_ring_one(FwdParams p, hipStream_t s) {
     constexpr int BM = NW * QB * 32;
     constexpr int smem = fwd_smem(D, RING, MODE, NW, QB);
     p.nqblk = (p.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, PRIO, 0, 0, RING, 0, SEED>;
+    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, PRIO, 0, RING, 0, SEED>;
     ensure_smem<kern>(smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(NW * 64), smem, s, p);
     return launch_rc();
@@ -159,38 +124,6 @@ int launch_fwd_w8_mode(const FwdParams& p, int mode, hipStream_t s) {
     return launch_fwd_ring_one<Tag, D, QB, MODE_CAUSAL, OCC, 0, PRIO, 0, 8>(p, s);
 }
 
-// key-block-split kernel (fasn_fwd_split.h)
-template <typename Tag, int D, int QB, int MODE, int OCC>
-int launch_fwd_split_one(FwdParams p, hipStream_t s) {
-    constexpr int BM = 4 * QB * 32;
-    constexpr int smem = 4 * KT * D * 2;
-    p.nqblk = (p.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_fwd_split_kernel<Tag, D, QB, MODE, OCC>;
-    ensure_smem<kern>(smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
-    return launch_rc();
-}
-template <typename Tag, int D, int QB, int OCC>
-int launch_fwd_split(const FwdParams& p, int mode, hipStream_t s) {
-    if (mode == MODE_PLAIN) return launch_fwd_split_one<Tag, D, QB, MODE_PLAIN, OCC>(p, s);
-    return launch_fwd_split_one<Tag, D, QB, MODE_CAUSAL, OCC>(p, s);
-}
-
-template <typename Tag, int D, int MODE, int OCC>
-int launch_fwd_pp_one(FwdParams p, hipStream_t s) {
-    constexpr int BM = 256;
-    constexpr int smem = 4 * KT * D * 2;
-    p.nqblk = (p.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_fwd_pp_kernel<Tag, D, MODE, OCC>;
-    ensure_smem<kern>(smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(512), smem, s, p);
-    return launch_rc();
-}
-template <typename Tag, int D, int OCC>
-int launch_fwd_pp_mode(const FwdParams& p, int mode, hipStream_t s) {
-    if (mode == MODE_PLAIN) return launch_fwd_pp_one<Tag, D, MODE_PLAIN, OCC>(p, s);
-    return launch_fwd_pp_one<Tag, D, MODE_CAUSAL, OCC>(p, s);
-}
 #endif  // FASN_DEV_VARIANTS
 
 }  // namespace fasn
