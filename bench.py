@@ -2,7 +2,7 @@
 """bench.py — headline benchmark of the hot path (BASELINE.json): attn-ops/s of flash_attention_n at
 (B=8, H=16, S=4096, D=64) bf16, n=1, non-causal, on N replicated GPUs (no sharding, no RCCL on the data path).
 
-  python bench.py --gpus N --steps K --warmup W [--workload m0|c1|c2|c3|c4|c5] [--pass fwd|bwd|fwdbwd] [--backward-plan split|one_pass]
+  python bench.py --gpus N --steps K --warmup W [--workload m0|c1|c2|c3|c4|c5|d256] [--pass fwd|bwd|fwdbwd] [--backward-plan split|one_pass]
 
 N > 1: bench.py launches its own N replica processes (one per GPU, gloo control plane over 127.0.0.1) when it is started
 without WORLD_SIZE; started under `python -m torch.distributed.run --nproc-per-node N ...` it joins that world instead.
@@ -37,6 +37,7 @@ WORKLOADS = {
     "c2": (8, 16, 1024, 64, "bf16", 1.0, False),
     "c3": (8, 16, 4096, 64, "f16", 1.0, True),
     "c5": (64, 16, 4096, 64, "bf16", 1.0, True),
+    "d256": (4, 16, 4096, 256, "bf16", 1.0, False),   # head dim 256 (not a BASELINE config: the reference API's "any E" served natively)
     "c4": (4, 32, 8192, 128, "bf16", 0.5, False),   # + dense ALiBi bias [H,L,S] and key-padding mask [B,1,1,S]
 }
 PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak, MI355X (MI355X_MICROARCH.md)
@@ -44,6 +45,9 @@ PEAK_TFLOPS_F32 = 157.3   # fp32-input MFMA (v_mfma_f32_32x32x2_f32) = the fp32 
 # GEMM-equivalents (one = 2*B*H*Sq*Sk*D flops): forward 2 (QK^T, PV); backward 5 in the textbook algorithm (S, dP, dV, dK, dQ),
 # 7 executed by the deterministic two-kernel split (S and dP are recomputed by both the dQ and the dK/dV kernel)
 GEMMS = {"fwd": (2, 2), "bwd": (5, 7), "fwdbwd": (7, 9)}
+# D = 256: two workgroups per row / key block each own half of the output features and both compute the scores: the forward
+# executes QK^T twice (3 for 2), the dK/dV kernel S and dP twice (6 for 4; + dQ's 3 = 9 for 5)
+GEMMS256 = {"fwd": (2, 3), "bwd": (5, 9), "fwdbwd": (7, 12)}
 
 
 def fwd_flops(B, H, S, D, causal):
@@ -55,7 +59,8 @@ def pass_flops(which, B, H, S, D, causal, visible_key_fraction=1.0):
     64-key tiles the kernels do not walk (C4) - the algorithmic count keeps SURVEY 8(d)'s definition (every score of the
     [S x S] grid), the executed count follows the tiles that actually run (checked against SQ_INSTS_MFMA in profiles/)."""
     g = fwd_flops(B, H, S, D, causal) / 2.0
-    return GEMMS[which][0] * g, GEMMS[which][1] * g * visible_key_fraction
+    gemms = GEMMS256 if D > 128 else GEMMS
+    return gemms[which][0] * g, gemms[which][1] * g * visible_key_fraction
 
 
 def visible_tile_fraction(B, S, tile=64):
@@ -314,7 +319,7 @@ def main():
             "traffic": pmc_traffic(args.workload, args.which), "kernel_ms": kernel_ms,
             "kernels": {"fwd": "fasn_fwd_kernel", "bwd": "fasn_bwd_delta + fasn_bwd_dq + fasn_bwd_dkdv", "fwdbwd": "fasn_fwd_kernel + the three backward kernels"}[args.which],
             "algorithmic_flops_per_launch": alg, "executed_flops_per_launch": exe,
-            "gemm_equivalents": {"algorithmic": GEMMS[args.which][0], "executed": GEMMS[args.which][1]},
+            "gemm_equivalents": {"algorithmic": (GEMMS256 if D > 128 else GEMMS)[args.which][0], "executed": (GEMMS256 if D > 128 else GEMMS)[args.which][1]},
             "frac_executed": exe / (kernel_ms * 1e-3) / 1e12 / peak,
             **({"visible_key_tile_fraction": vis} if vis < 1.0 else {})}
         if args.backward_plan == "one_pass" and args.which != "fwd":
@@ -359,7 +364,7 @@ def main():
         line["max_abs_err"] = float((out[0:nb, :hs].float().cpu() - ref.float()).abs().max())
         ref32 = ref_attention_n(qc[:, :2].float(), kc[:, :2].float(), vc[:, :2].float(), softmax_n_param=n, is_causal=causal,
                                 attn_bias=None if bc is None else bc[:2].float(), attn_mask=mc)
-        line["max_abs_err_vs_fp32_oracle"] = float((out[0:1, :2].float().cpu() - ref32).abs().max())
+        line["max_abs_err_vs_fp32_oracle"] = float((out[0:nb, :2].float().cpu() - ref32).abs().max())
     print(json.dumps(line), flush=True)
     ctl.close()
 

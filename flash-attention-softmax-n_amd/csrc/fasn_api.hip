@@ -156,7 +156,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
 // would walk many key tiles. Returns the number of key splits (1 = do not split) and the tiles per split (even).
 int plan_splitk(const fasn_fwd_args* a, const FwdParams& p, const FwdLaunch& l, int& tps) {
     tps = 0;
-    if (l.dtype == FASN_DTYPE_F32 || p.drop_thr || l.mode == MODE_GENERAL_SLOW) return 1;
+    if (l.dtype == FASN_DTYPE_F32 || p.drop_thr || l.mode == MODE_GENERAL_SLOW || l.D > 128) return 1;
     if ((l.mode == MODE_KEYPAD || l.mode == MODE_BIAS_KEYPAD) && p.keypad_fallback == MODE_GENERAL_SLOW) return 1;
     const int64_t base_blocks = (int64_t)a->B * a->H * ((a->Sq + 127) / 128);
     int ntiles = (a->Sk + KT - 1) / KT;
@@ -183,6 +183,7 @@ int dispatch_fwd(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 32: return launch_fwd_d32(p, l, s);
         case 64: return launch_fwd_d64(p, l, s);
         case 128: return launch_fwd_d128(p, l, s);
+        case 256: return launch_fwd_d256(p, l, s);
         default: return FASN_EHEADDIM;
     }
 }
@@ -216,7 +217,7 @@ const char* fasn_strerror(int code) {
         case FASN_OK: return "ok";
         case FASN_EINVAL: return "invalid argument (null pointer, non-positive size, negative n/scale, bad enum)";
         case FASN_EDTYPE: return "unsupported element type (supported: fp16, bf16, fp32)";
-        case FASN_EHEADDIM: return "unsupported head dimension (supported: D == Dv in {32, 64, 128})";
+        case FASN_EHEADDIM: return "unsupported head dimension (supported: D == Dv in {32, 64, 128}, and 256 for fp16 / bf16)";
         case FASN_EALIGN: return "pointer or stride breaks the 16-byte row alignment rule";
         case FASN_ESTRIDE: return "feature (last-dim) stride must be 1";
         case FASN_ELAUNCH: return "kernel launch failed";
@@ -229,6 +230,7 @@ const char* fasn_strerror(int code) {
 int fasn_supported(int32_t dtype, int32_t D, int32_t Dv) {
     if (dtype != FASN_DTYPE_F16 && dtype != FASN_DTYPE_BF16 && dtype != FASN_DTYPE_F32) return 0;
     if (D != Dv) return 0;
+    if (D == 256) return dtype != FASN_DTYPE_F32 ? 1 : 0;   // 16-bit MFMA kernels only at this head dim
     return (D == 32 || D == 64 || D == 128) ? 1 : 0;
 }
 

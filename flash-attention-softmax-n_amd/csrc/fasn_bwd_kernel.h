@@ -133,7 +133,7 @@ struct TileDma {
 #ifndef FASN_DQ_SEED_D32
 #define FASN_DQ_SEED_D32 2
 #endif
-template <typename Tag, int D, int QB, int MODE, int OCC, int DROP = 0, int DQ_SEED = (D == 128 ? FASN_DQ_SEED_D128 : D == 32 ? FASN_DQ_SEED_D32 : 3)>
+template <typename Tag, int D, int QB, int MODE, int OCC, int DROP = 0, int DQ_SEED = (D >= 128 ? FASN_DQ_SEED_D128 : D == 32 ? FASN_DQ_SEED_D32 : 3)>
 __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams bp) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -567,7 +567,9 @@ constexpr int QT = 64;  // query rows per tile
 
 // GQA = 1 (grouped-query attention, kvg query heads per K/V head): one workgroup per (batch, K/V head, key block) walks the q-tiles
 // of all query heads of its group, one head after the other, into the same fp32 accumulators: dK / dV come out per K/V head.
-template <typename Tag, int D, int KB, int MODE, int OCC, int DROP = 0, int GQA = 0>
+// DH = 2 (D = 256): two workgroups per key block, each with the full S / dP but HALF of the features of dK and dV (2 x 64 instead of
+// 2 x 128 accumulator registers); the grid is doubled, block 2j + v owns feature half v.
+template <typename Tag, int D, int KB, int MODE, int OCC, int DROP = 0, int GQA = 0, int DH = 1>
 __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams bp) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -575,7 +577,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     constexpr int BN = 4 * KB * 32;
     constexpr int TILEB = QT * D * 2;
     constexpr int KS = D / 16;
-    constexpr int DB = D / 32;
+    constexpr int DB = D / 32 / DH;   // feature blocks of this workgroup
     constexpr int NLD = (QT * (D / 8)) / 256;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -594,7 +596,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     const int kvg = GQA ? p.kvg : 1;
     const int Hkv = p.H / kvg;
     int bhk, kblk;
-    block_to_work(blockIdx.x, p.B * Hkv, bp.nblk, bhk, kblk);
+    const int d0 = DH > 1 ? (int)(blockIdx.x % DH) * DB : 0;   // first feature block of this workgroup
+    block_to_work(DH > 1 ? (int)(blockIdx.x / DH) : (int)blockIdx.x, p.B * Hkv, bp.nblk, bhk, kblk);
     const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
     const int b = bhk / Hkv, hk = bhk % Hkv;
     const int kw0 = kblk * BN + wave * (KB * 32);  // first key of this wave
@@ -952,8 +955,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                     for (int d = 0; d < DB; ++d) {
-                        vec8 dot = lds_read_trfrag<E, D>(tD, qb * 32 + 16 * t2, d, lane);
-                        vec8 qt = lds_read_trfrag<E, D>(tQ, qb * 32 + 16 * t2, d, lane);
+                        vec8 dot = lds_read_trfrag<E, D>(tD, qb * 32 + 16 * t2, d0 + d, lane);
+                        vec8 qt = lds_read_trfrag<E, D>(tQ, qb * 32 + 16 * t2, d0 + d, lane);
 #pragma unroll
                         for (int kb = 0; kb < KB; ++kb) {
                             dvacc[kb][d] = E::mfma(dot, pfr[kb][t2], dvacc[kb][d]);
@@ -1006,8 +1009,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                     u32x2 ra, rb;
                     __builtin_memcpy(&ra, &xk, 8);
                     __builtin_memcpy(&rb, &yv, 8);
-                    gstore8(rk + (d * 32 + 8 * g + 4 * hi) * 2, ra);
-                    gstore8(rv + (d * 32 + 8 * g + 4 * hi) * 2, rb);
+                    gstore8(rk + ((d0 + d) * 32 + 8 * g + 4 * hi) * 2, ra);
+                    gstore8(rv + ((d0 + d) * 32 + 8 * g + 4 * hi) * 2, rb);
                 }
         }
     }

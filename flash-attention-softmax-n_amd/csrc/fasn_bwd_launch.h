@@ -12,6 +12,7 @@ int launch_bwd(const BwdParams& p, const FwdLaunch& l, hipStream_t s);  // delta
 int launch_bwd_d32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d128(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
+int launch_bwd_d256(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_fused_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);   // one-pass backward (fasn_bwd_fused.h), p.dqacc set
 
 // developer switch (FASN_DEV_VARIANTS builds only): bit 0 = take the one-wave dK/dV kernel where the two-wave kernel is the default,
@@ -24,7 +25,7 @@ extern int g_bwd_variant;
 #endif
 
 // WS = 1: dK / dV by the two-wave kernel (fasn_bwd_dkdv_ws.h); not for dropout or the element-load mode
-template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, int DROP = 0, int WS = 0>
+template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, int DROP = 0, int WS = 0, int DH = 1>
 int launch_bwd_one(BwdParams p, hipStream_t s) {
     const int nbh = p.f.B * p.f.H;
     {   // delta
@@ -73,13 +74,13 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (mode_is_vector(MODE) ? 2 * QT * BN * 2 : 0);
         p.nblk = (p.f.Sk + BN - 1) / BN;
         if (p.f.kvg > 1) {
-            constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 1>;
+            constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 1, DH>;
             ensure_smem<kern>(smem);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(256), smem, s, p);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg) * DH)), dim3(256), smem, s, p);
         } else {
-            constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 0>;
+            constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 0, DH>;
             ensure_smem<kern>(smem);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh * DH)), dim3(256), smem, s, p);
         }
     }
     return launch_rc();

@@ -81,12 +81,13 @@ struct ET<f16_tag> {
 //   (2) ds_read_b64_tr_b16 "4 consecutive rows x 32 contiguous columns per half-wave"
 //       (MFMA operand with the contraction along rows), serviced per 32 lanes.
 // chunk' = chunk ^ f(row):
+//   D=256 (512-B rows, two bank-rows each): as D=128 - the XOR stays inside a 256-byte half row
 //   D=128 (256-B rows, one bank-row each):  f = ((row&3)<<2) | ((row>>2)&3)
 //   D=64  (128-B rows, two per bank-row):   f = (bit1(row)<<2) | (bit2(row)<<1) | bit3(row)
 //   D=32  (64-B rows, four per bank-row):   f = (row>>2)&3
 template <int D>
 FASN_DEV int swz_f(int row) {
-    if constexpr (D == 128) {
+    if constexpr (D == 128 || D == 256) {
         return ((row & 3) << 2) | ((row >> 2) & 3);
     } else if constexpr (D == 64) {
         return ((row & 2) << 1) | ((row >> 1) & 2) | ((row >> 3) & 1);

@@ -1,0 +1,24 @@
+// D = 256 forward instantiations (the reference API serves any head dim through SDPA, core/flash_attn.py:117-124).
+// One wave per SIMD (4-wave workgroups, 32 query rows per wave, the whole register file): Q^T fragments are 64 registers and a
+// full O^T accumulator would be 128 more - the kernel spilled - so two workgroups share a query block, each with the full QK^T
+// and softmax but half of the output features (VH = 2: 1.5 x the flops, no spills); K/V tiles of 64 keys (32 KiB each) are
+// register-staged into two LDS buffers. Mask / bias: the vector kernel serves every combination (an absent operand is a
+// zero-range descriptor / an all-ones word), key padding rides the plain kernel, everything else the element-load kernel.
+#include "fasn_launch.h"
+namespace fasn {
+template <typename Tag>
+static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (p.drop_thr) return launch_fwd_one<Tag, 256, 1, MODE_GENERAL_SLOW, 1, 4, 0, 0, 1, 2>(p, s);   // dropout: the element-load kernel
+    const int mode = l.mode == MODE_BIAS_KEYPAD ? p.keypad_fallback : l.mode;   // bias + key padding: the dense-mask view of the same mask
+    switch (mode) {
+        case MODE_PLAIN: return launch_fwd_one<Tag, 256, 1, MODE_PLAIN, 1, 4, 0, 2, 0, 2>(p, s);
+        case MODE_CAUSAL: return launch_fwd_one<Tag, 256, 1, MODE_CAUSAL, 1, 4, 0, 2, 0, 2>(p, s);
+        case MODE_KEYPAD: return launch_fwd_one<Tag, 256, 1, MODE_KEYPAD, 1, 4, 0, 2, 0, 2>(p, s);
+        case MODE_GENERAL: case MODE_GENERAL_B: case MODE_GENERAL_M: return launch_fwd_one<Tag, 256, 1, MODE_GENERAL, 1, 4, 0, 2, 0, 2>(p, s);
+        default: return launch_fwd_one<Tag, 256, 1, MODE_GENERAL_SLOW, 1, 4, 0, 0, 0, 2>(p, s);
+    }
+}
+int launch_fwd_d256(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    return l.dtype == 1 ? go<bf16_tag>(p, l, s) : go<f16_tag>(p, l, s);
+}
+}  // namespace fasn

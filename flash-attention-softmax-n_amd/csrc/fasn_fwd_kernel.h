@@ -126,10 +126,13 @@ FASN_DEV void kp_build_words(uint64_t* words, const uint8_t* mrow, int Sk, int n
 // RING: 2 = no staging registers at all: `buffer_load_dwordx4 ... lds` moves each 16-byte chunk straight from HBM/L2 into
 // the LDS tile image (LDS address = wave base + 16*lane, so the swizzle is applied by choosing WHICH global chunk a lane
 // fetches), three LDS tile buffers, loads issued two tiles ahead, `s_waitcnt vmcnt` before the barrier that publishes a tile.
-template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int DROP = 0, int RING = 0, int SPLIT = 0, int SEED = 0>
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int DROP = 0, int RING = 0, int SPLIT = 0, int SEED = 0, int VH = 1>
 __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
     static_assert(!SEED || MODE != MODE_GENERAL_SLOW, "seeded accumulators: not for the element-load kernels");
     static_assert(!SPLIT || (RING != 1 && DROP == 0), "split-K: single-set or direct-to-LDS staging");
+    // VH = 2 (D = 256): two workgroups per query block, each with the full QK^T and softmax but HALF of the output features
+    // (O^T for 128 features is 64 accumulator registers instead of 128); the grid is doubled, block 2j + v owns feature half v.
+    static_assert(VH == 1 || (VH == 2 && !SPLIT), "feature halves: not with split-K");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     constexpr bool PSUM = SEED >= 2 && !DROP;   // fast-path row sums from the packed weights
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     constexpr int ROWB = D * 2;
     constexpr int TILEB = KT * ROWB;
     constexpr int KS = D / 16;   // k-steps of QK^T
-    constexpr int DB = D / 32;   // 32-wide output column blocks
+    constexpr int DB = D / 32 / VH;   // 32-wide output column blocks of this workgroup
     constexpr int CPR = D / 8;   // 16-B chunks per row
     constexpr int NLD = (KT * CPR) / NT;  // staging loads per thread per tensor
     static_assert(NLD >= 1, "tile too small for this workgroup size");
@@ -157,6 +160,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int hi = lane >> 5;
 
     int bh, qi, split = 0;
+    const int wgid = VH > 1 ? (int)(blockIdx.x / VH) : (int)blockIdx.x;
+    const int dv0 = VH > 1 ? (int)(blockIdx.x % VH) * DB : 0;   // first output column block of this workgroup
     constexpr bool VEC = mode_is_vector(MODE);
     constexpr bool SLOW = MODE == MODE_GENERAL_SLOW;
     constexpr bool GEN = VEC || SLOW;
@@ -169,17 +174,17 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     constexpr bool KP = mode_has_keypad(MODE);
     if (SPLIT) {
         int blk;
-        block_to_work(blockIdx.x, p.B * p.H, p.nqblk * p.nsplit, bh, blk);
+        block_to_work(wgid, p.B * p.H, p.nqblk * p.nsplit, bh, blk);
         qi = blk / p.nsplit;
         split = blk % p.nsplit;
     } else if (GEN && p.batch_inner && (p.H & 7) == 0) {
         // per XCD: (head, q-block, batch) with the batch fastest -> the B workgroups that read the same bias tile run together
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int xcd = wgid & 7, j = wgid >> 3;
         const int bb = j % p.B, rest = j / p.B;
         qi = rest % p.nqblk;
         bh = bb * p.H + (rest / p.nqblk) * 8 + xcd;
     } else {
-        block_to_work(blockIdx.x, p.B * p.H, p.nqblk, bh, qi);
+        block_to_work(wgid, p.B * p.H, p.nqblk, bh, qi);
     }
     // causal: heaviest (last) query blocks first
     const int qblk = (MODE != MODE_PLAIN && p.causal) ? (p.nqblk - 1 - qi) : qi;
@@ -774,7 +779,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                     for (int d = 0; d < DB; ++d) {
-                        const vec8 vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, d, lane);
+                        const vec8 vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, dv0 + d, lane);
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
                     }
@@ -852,7 +857,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         const float l_tot = sum_across_halves(l_run[qb]);
         const float inv = l_tot > 0.f ? (DROP ? p.drop_scale : 1.0f) / l_tot : 0.f;
         if (row < p.Sq) {
-            if (p.lse != nullptr && hi == 0) {
+            if (p.lse != nullptr && hi == 0 && dv0 == 0) {
                 const float m_use = (m_run[qb] == -INFINITY) ? 0.f : m_run[qb];
                 p.lse[(int64_t)bh * p.Sq + row] = l_tot > 0.f ? (m_use + __builtin_log2f(l_tot)) * kLn2 : -INFINITY;
             }
@@ -867,7 +872,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     typename E::vec4 y = E::cvt4(x);
                     u32x2 raw;
                     __builtin_memcpy(&raw, &y, 8);
-                    gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
+                    gstore8(rp + ((dv0 + d) * 32 + 8 * g + 4 * hi) * 2, raw);
                 }
         }
     }

@@ -19,6 +19,7 @@ struct FwdLaunch {
 int launch_fwd_d32(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_fwd_d64(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_fwd_d128(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
+int launch_fwd_d256(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_fwd_splitk(const FwdParams& p, const FwdLaunch& l, hipStream_t s);   // p.nsplit > 1, partial buffers set
 
 // A kernel that needs more than 48 KiB of dynamic LDS must be told so once per (kernel, device). The attribute is per
@@ -43,14 +44,14 @@ constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB) {
 }
 
 // one instantiation of the forward kernel: NW waves x QB 32-row blocks per wave, staging scheme RING, accumulator seeding SEED
-template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int RING = 0, int SEED = 0, int DROP = 0>
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int RING = 0, int SEED = 0, int DROP = 0, int VH = 1>
 int launch_fwd_one(FwdParams p, hipStream_t s) {
     constexpr int BM = NW * QB * 32;
     constexpr int smem = fwd_smem(D, RING, MODE, NW, QB);
     p.nqblk = (p.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, 0, DROP, RING, 0, SEED>;
+    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, 0, DROP, RING, 0, SEED, VH>;
     ensure_smem<kern>(smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(NW * 64), smem, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H * VH)), dim3(NW * 64), smem, s, p);
     return launch_rc();
 }
 

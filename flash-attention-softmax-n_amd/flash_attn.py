@@ -19,7 +19,7 @@ from torch import Tensor
 from . import _lib
 from ._lib import BwdArgs, FwdArgs, View4
 
-_SUPPORTED_D = (32, 64, 128)
+_SUPPORTED_D = (32, 64, 128, 256)
 _DTYPES = {torch.float16: _lib.FASN_DTYPE_F16, torch.bfloat16: _lib.FASN_DTYPE_BF16, torch.float32: _lib.FASN_DTYPE_F32}
 
 
@@ -332,10 +332,11 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
     if scale < 0:  # exp2 folding assumes scale >= 0: move the sign into q
         query, scale = -query, -scale
 
-    # feature dims: kernels exist for D == Dv in {32, 64, 128}; anything else is zero-padded (exact)
-    dpad = next((d for d in _SUPPORTED_D if d >= max(E, Ev)), None)
+    # feature dims: kernels exist for D == Dv in {32, 64, 128} and (fp16 / bf16) 256; anything else is zero-padded (exact)
+    dmax = 128 if query.dtype == torch.float32 else 256
+    dpad = next((d for d in _SUPPORTED_D if max(E, Ev) <= d <= dmax), None)
     if dpad is None:
-        raise NotImplementedError(f"head dim {max(E, Ev)} > 128 is not supported")
+        raise NotImplementedError(f"head dim {max(E, Ev)} > {dmax} is not supported for {query.dtype}")
     if E == dpad and Ev == dpad:
         q, k, v = _canon(query), _canon(key), _canon(value)
     else:

@@ -47,8 +47,9 @@ def test_abi_version_and_strerror(pkg):
 
 def test_supported_matrix(pkg):
     lib = pkg._lib.load()
-    for d in (32, 64, 128):
+    for d in (32, 64, 128, 256):
         assert lib.fasn_supported(0, d, d) == 1 and lib.fasn_supported(1, d, d) == 1
+    assert lib.fasn_supported(2, 256, 256) == 0 and lib.fasn_supported(1, 512, 512) == 0   # fp32 stops at 128, 16-bit at 256
     assert lib.fasn_supported(1, 64, 32) == 0
     assert lib.fasn_supported(1, 96, 96) == 0
     assert lib.fasn_supported(2, 64, 64) == 1 and lib.fasn_supported(3, 64, 64) == 0

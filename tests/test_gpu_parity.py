@@ -274,9 +274,46 @@ def test_one_pass_plan_is_opt_in_and_falls_back(pkg, dev):
         pkg.set_backward_plan(prev)
 
 
+# ---------------------------------------------------------------- head dims above 128 (the reference API serves any E through SDPA)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["plain", "causal", "bias", "keypad+causal"])
+@pytest.mark.parametrize("shape", [(2, 8, 1024, 1024, 256), (1, 2, 200, 333, 160), (2, 2, 77, 100, 192), (1, 1, 3, 5, 256)])
+def test_head_dim_256(pkg, dev, shape, kind, dtype):
+    """core/flash_attn.py:117-124 takes any head dim; here D in (128, 256] runs the D = 256 kernels (zero-padded features), forward
+    and backward, against the oracle: (2,8,1024,256) plain / causal / ALiBi bias, ragged sizes, L != S."""
+    B, H, L, S, D = shape
+    n = 0.5
+    q = _rand((B, H, L, D), dtype, dev, 31).requires_grad_()
+    k, v = (_rand((B, H, S, D), dtype, dev, s_).requires_grad_() for s_ in (32, 33))
+    do = _rand((B, H, L, D), dtype, dev, 34, std=1.0)
+    kw = {}
+    if kind == "bias":
+        kw["attn_bias"] = synth.alibi_bias(H, L, S, dtype, device=dev)
+    if kind in ("causal", "keypad+causal"):
+        kw["is_causal"] = True
+    if kind == "keypad+causal":
+        kw["attn_mask"] = synth.keypad_mask(B, S, device=dev)
+        n = 1.0
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, **kw)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=n, **kw)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"D={D} {kind} {nm}")
+
+
+def test_head_dim_limits(pkg, dev):
+    """above 256 (16-bit) / 128 (fp32) the call is refused with the reason, not served by a fallback"""
+    q = torch.zeros(1, 1, 8, 264, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(NotImplementedError):
+        pkg.flash_attention_n(q, q, q)
+    q32 = torch.zeros(1, 1, 8, 160, dtype=torch.float32, device=dev)
+    with pytest.raises(NotImplementedError):
+        pkg.flash_attention_n(q32, q32, q32)
+
+
 # ---------------------------------------------------------------- masks, bias, layouts, edge cases
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("D", [32, 64, 128, 256])
 @pytest.mark.parametrize("kind", ["keypad", "dense", "bias3d", "bias4d_f32", "all"])
 def test_mask_bias_combinations(pkg, dev, kind, D, dtype):
     B, H, L, S = 2, 3, 200, 264

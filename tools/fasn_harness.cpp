@@ -453,6 +453,11 @@ static int do_test(int variant, bool quick) {
         {"d128 bf16 alibi+keypad n.5", mk(2, 4, 320, 320, 128, BF, 0, 0.5f, 1, 1), true},
         {"d64 f16 f32bias+mask causal n1", mk(1, 2, 130, 190, 64, HF, 1, 1.f, 2, 2), true},
         {"d64 bf16 scale.3 n4", mk(1, 1, 1024, 1152, 64, BF, 0, 4.f, 0, 0, 0.3f), true},
+        {"d256 bf16 256x320 n.5", mk(1, 2, 256, 320, 256, BF, 0, 0.5f), true},
+        {"d256 f16 257x129 causal n1", mk(1, 2, 257, 129, 256, HF, 1, 1.f), true},
+        {"d256 bf16 keypad n1", mk(2, 2, 200, 264, 256, BF, 0, 1.f, 1, 0), true},
+        {"d256 bf16 alibi+keypad n.5", mk(2, 4, 320, 320, 256, BF, 0, 0.5f, 1, 1), true},
+        {"d256 f16 f32bias+mask causal n1", mk(1, 2, 130, 190, 256, HF, 1, 1.f, 2, 2), true},
         {"d64 bf16 1100x1300 causal n1", mk(1, 2, 1100, 1300, 64, BF, 1, 1.f), true},
         {"d64 f16 1300x1100 causal n0", mk(1, 2, 1300, 1100, 64, HF, 1, 0.f), true},
         {"d64 f16 33x1000 n1", mk(2, 2, 33, 1000, 64, HF, 0, 1.f), true},
