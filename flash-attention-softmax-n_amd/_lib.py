@@ -48,6 +48,7 @@ class BwdArgs(Structure):
         ("delta", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("dbias", View4),
         ("flags", c_int32),
+        ("dbias_dtype", c_int32),
     ]
 
 

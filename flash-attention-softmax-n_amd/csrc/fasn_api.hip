@@ -337,15 +337,22 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
     p.dbias = nullptr;
     p.dbias_vec = 0;
     for (int i = 0; i < 3; ++i) p.dbs[i] = 0;
+    bool dbias_reduced = false;
+    int dbias_f32 = 0;
     if (a->dbias.ptr != nullptr) {
         if (a->fwd.bias.ptr == nullptr) return FASN_EINVAL;   // nothing to differentiate
         if (a->dbias.stride[3] != 1) return FASN_ESTRIDE;
-        if (reinterpret_cast<uintptr_t>(a->dbias.ptr) % esize) return FASN_EALIGN;
+        // reduced form: the gradient summed over a broadcast batch and / or head dimension by the dbias kernel
+        dbias_reduced = (a->dbias.stride[0] == 0 && a->fwd.B > 1) || (a->dbias.stride[1] == 0 && a->fwd.H > 1);
+        if (dbias_reduced && (l.dtype == FASN_DTYPE_F32 || fp.drop_thr != 0 || a->dbias.stride[2] == 0)) return FASN_EUNSUPPORTED;
+        dbias_f32 = (dbias_reduced && a->dbias_dtype == FASN_BIAS_F32) ? 1 : 0;
+        const int osz = dbias_f32 ? 4 : esize;
+        if (reinterpret_cast<uintptr_t>(a->dbias.ptr) % osz) return FASN_EALIGN;
         p.dbias = (char*)a->dbias.ptr;
         bool vec = reinterpret_cast<uintptr_t>(a->dbias.ptr) % 16 == 0;
         for (int i = 0; i < 3; ++i) {
             p.dbs[i] = a->dbias.stride[i];
-            vec = vec && (a->dbias.stride[i] * esize) % 16 == 0;
+            vec = vec && (a->dbias.stride[i] * osz) % 16 == 0;
         }
         p.dbias_vec = vec ? 1 : 0;
     }
@@ -356,6 +363,13 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
         p.dvs[i] = a->dv.stride[i];
     }
     if (l.dtype == FASN_DTYPE_F32) return launch_bwd_f32(p, l, (hipStream_t)stream);
+    if (dbias_reduced) {   // dQ / dK / dV without the dense dS store, then the bias gradient by its own kernel (it needs delta)
+        BwdParams pg = p;
+        pg.dbias = nullptr;
+        const int rc2 = launch_bwd(pg, l, (hipStream_t)stream);
+        if (rc2) return rc2;
+        return launch_bwd_dbias(p, l, a->dbias.stride[0] == 0 ? 1 : a->fwd.B, a->dbias.stride[1] == 0 ? 1 : a->fwd.H, dbias_f32, (hipStream_t)stream);
+    }
     return launch_bwd(p, l, (hipStream_t)stream);
 }
 

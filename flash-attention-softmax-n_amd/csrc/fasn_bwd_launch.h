@@ -14,6 +14,7 @@ int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d128(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d256(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_fused_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);   // one-pass backward (fasn_bwd_fused.h), p.dqacc set
+int launch_bwd_dbias(const BwdParams& p, const FwdLaunch& l, int Bb, int Hb, int out_f32, hipStream_t s);   // batch- / head-reduced bias gradient (fasn_bwd_dbias.h)
 
 // developer switch (FASN_DEV_VARIANTS builds only): bit 0 = take the one-wave dK/dV kernel where the two-wave kernel is the default,
 // bit 1 = the same for dQ

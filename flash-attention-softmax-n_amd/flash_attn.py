@@ -228,10 +228,13 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
     """autograd glue; same role as _FlashAttentionN (flash_attn_triton.py:241-336)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, bias, n: float, scale: float, causal: bool, dropout_p: float = 0.0, rng=None):
-        o, lse = _launch_fwd(q, k, v, mask, bias, n, scale, causal, dropout_p, rng)
+    def forward(ctx, q, k, v, mask, bias, n: float, scale: float, causal: bool, dropout_p: float = 0.0, rng=None, bias_small: bool = False):
+        # bias_small: `bias` is the caller's [1 or B, 1 or H, L, S] tensor, not yet expanded - its gradient then comes back in that
+        # shape, summed over the broadcast batch / head dimensions inside the dbias kernel (no [B,H,L,S] buffer)
+        bias_k = bias.expand(q.shape[0], q.shape[1], q.shape[2], k.shape[2]) if bias_small else bias
+        o, lse = _launch_fwd(q, k, v, mask, bias_k, n, scale, causal, dropout_p, rng)
         ctx.save_for_backward(q, k, v, o, lse, mask, bias)
-        ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, ctx.rng = n, scale, causal, dropout_p, rng
+        ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, ctx.rng, ctx.bias_small = n, scale, causal, dropout_p, rng, bias_small
         return o
 
     @staticmethod
@@ -242,6 +245,9 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         B, H, L, D = q.shape
         S = k.shape[2]
         dev = q.device
+        bias_small = bias if ctx.bias_small else None
+        if ctx.bias_small:
+            bias = bias.expand(B, H, L, S)
         dq = torch.empty((B, H, L, D), dtype=q.dtype, device=dev)
         Hkv = k.shape[1]   # grouped-query attention: each dK/dV workgroup sums the query heads of its K/V head in registers
         dk = torch.empty((B, Hkv, S, D), dtype=q.dtype, device=dev)
@@ -269,9 +275,15 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         # gradient of attn_bias: the kernel writes dS densely; autograd sums it over the dimensions the caller's bias broadcasts
         # (the expand / unsqueeze / dtype cast in _attention are ordinary autograd ops)
         dbias = None
+        a.dbias_dtype = 0
         if bias is not None and ctx.needs_input_grad[4]:
-            dbias = torch.zeros((B, H, L, S), dtype=q.dtype, device=dev)   # tiles the causal walk skips are never written
-            a.dbias = _view4(dbias)
+            if bias_small is not None:   # reduced form: the kernel sums over the bias's broadcast batch / head dimensions
+                dbias = torch.empty(bias_small.shape, dtype=bias_small.dtype, device=dev)
+                a.dbias = _view4(dbias)   # (size-1 dimensions get stride 0 = "reduce over this dimension")
+                a.dbias_dtype = _lib.FASN_BIAS_F32 if dbias.dtype == torch.float32 else _lib.FASN_BIAS_SAME
+            else:
+                dbias = torch.zeros((B, H, L, S), dtype=q.dtype, device=dev)   # tiles the causal walk skips are never written
+                a.dbias = _view4(dbias)
         else:
             a.dbias.ptr = None
         with torch.cuda.device(dev):
@@ -283,7 +295,7 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
             a.dout = _view4(o)   # restore the cached block's default strides
         if dbias is not None and dbias.dtype != bias.dtype:
             dbias = dbias.to(bias.dtype)
-        return dq, dk, dv, None, dbias, None, None, None, None, None
+        return dq, dk, dv, None, dbias, None, None, None, None, None, None
 
 
 def _pad_feature(t: Tensor, d: int) -> Tensor:
@@ -356,10 +368,18 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
             raise ValueError("attn_bias must be [H, L, S] or broadcastable to [B, H, L, S]")
         if bias.dtype not in (query.dtype, torch.float32):
             bias = bias.to(query.dtype)
-        bias = bias.expand(B, H, L, S)
+        # a bias that needs a gradient and broadcasts over batch and / or heads only ([H,L,S], [1,H,L,S], [B,1,L,S], [1,1,L,S]) keeps
+        # its own shape: fasn_bwd then returns the gradient already summed over those dimensions (csrc/fasn_bwd_dbias.h)
+        bias_small = (bias.requires_grad and torch.is_grad_enabled() and dropout_p == 0.0 and query.dtype != torch.float32
+                      and bias.shape[2] == L and bias.shape[3] == S and bias.shape[0] in (1, B) and bias.shape[1] in (1, H)
+                      and ((bias.shape[0] == 1 and B > 1) or (bias.shape[1] == 1 and H > 1)) and bias.stride(3) == 1)
+        if not bias_small:
+            bias = bias.expand(B, H, L, S)
 
     # dropout: this call's (seed, offset) (see _next_rng_state); the kernels derive every keep/drop bit from
     # (seed, offset, b, h, row, key) - dropout.py is the host mirror
+    if bias is None:
+        bias_small = False
     rng = _next_rng_state(query.device) if dropout_p > 0.0 else None
     _attention.last_rng_state = rng
     Hkv = k.shape[1]
@@ -370,7 +390,7 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
         G = H // Hkv
         try:
             mask_g = None if mask is None else mask.view(B, Hkv, G, S)
-            bias_g = None if bias is None else bias.view(B, Hkv, G, S)
+            bias_g = None if bias is None else bias.expand(B, H, L, S).view(B, Hkv, G, S)
         except RuntimeError:      # strides that cannot be regrouped without a copy: keep the per-head launch
             mask_g = bias_g = False
         if mask_g is not False:
@@ -380,7 +400,7 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
     if not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad or (bias is not None and bias.requires_grad))):
         out = _launch_fwd(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, rng)[0]   # nothing to differentiate: no autograd node
     else:
-        out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, rng)
+        out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, rng, bias_small)
     return out if Ev == dpad else out[..., :Ev]
 
 

@@ -122,9 +122,14 @@ typedef struct fasn_bwd_args {
     float* delta;      /* [B,H,Sq] fp32 scratch */
     void* workspace;
     size_t workspace_bytes;
-    fasn_view4 dbias;  /* optional out (ABI 2): gradient of the additive bias = dS, dense [B,H,Sq,Sk] in `dtype`, key stride 1;
-                          ptr NULL = not wanted. Needs fwd.bias; the caller sums over the dimensions its bias broadcasts. */
+    fasn_view4 dbias;  /* optional out (ABI 2): gradient of the additive bias, key stride 1; ptr NULL = not wanted. Needs fwd.bias.
+                          Dense form: dS as [B,H,Sq,Sk] in `dtype` (the dQ kernels store it; the caller sums over whatever its
+                          bias broadcasts). Reduced form (ABI 4): a batch and / or head stride of 0 (with B > 1 / H > 1) asks for the
+                          sum over that dimension - dbias is then [1 or B, 1 or H, Sq, Sk], written once by a kernel that walks
+                          the (b,h) sharing each bias tile (csrc/fasn_bwd_dbias.h; 16-bit q/k/v, no dropout; no [B,H,Sq,Sk]
+                          buffer anywhere). */
     int32_t flags;     /* ABI 4: FASN_BWD_* bits, 0 = default */
+    int32_t dbias_dtype; /* ABI 4, reduced form only: FASN_BIAS_SAME (0 means the same) = `dtype`, FASN_BIAS_F32 = fp32 elements */
 } fasn_bwd_args;
 
 int fasn_abi_version(void);

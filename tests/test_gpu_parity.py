@@ -963,6 +963,73 @@ def test_attn_bias_gradient(pkg, dev, D, kind, dtype):
             _check(got, want, dtype, f"{kind}/{nm}")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D", [32, 64, 128, 256])
+@pytest.mark.parametrize("kind", ["hls", "1hls+causal", "b1ls+keypad", "11ls_f32+densemask", "hls_ragged"])
+def test_attn_bias_gradient_reduced_in_kernel(pkg, dev, kind, D, dtype):
+    """A bias that broadcasts over batch and / or heads gets its gradient from csrc/fasn_bwd_dbias.h: summed over those dimensions
+    inside the kernel, written once in the bias's shape and dtype (reference: SDPA differentiates the additive mask,
+    core/flash_attn.py:100-113). Against the oracle's autograd, with causal / key-padding / dense masks and ragged sizes."""
+    B, H, L, S = (3, 2, 150, 203) if kind != "hls_ragged" else (2, 3, 129, 131)
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    gen = torch.Generator().manual_seed(11)
+    mask, causal = None, False
+    if kind in ("hls", "hls_ragged"):
+        bias = torch.randn(H, L, S, generator=gen).to(dtype)
+    elif kind == "1hls+causal":
+        bias, causal = torch.randn(1, H, L, S, generator=gen).to(dtype), True
+    elif kind == "b1ls+keypad":
+        bias, mask = torch.randn(B, 1, L, S, generator=gen).to(dtype), synth.keypad_mask(B, S, device=dev)
+    else:
+        bias = torch.randn(1, 1, L, S, generator=gen)
+        mask = (torch.rand(B, H, L, S, generator=gen) < 0.7).to(dev)
+    bias = bias.to(dev).requires_grad_()
+    torch.cuda.reset_peak_memory_stats()
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, attn_bias=bias, attn_mask=mask, is_causal=causal)
+    base = torch.cuda.memory_allocated()
+    out.backward(do)
+    # no [B,H,L,S] buffer: the backward's extra memory stays below the gradients themselves + one bias-sized tensor + slack
+    extra = torch.cuda.max_memory_allocated() - base
+    small = 4 * q.numel() * q.element_size() + 2 * bias.numel() * bias.element_size() + (1 << 20)
+    assert extra <= small, f"backward peaked {extra} bytes above the forward state (limit {small}): a dense dS buffer?"
+    assert bias.grad is not None and bias.grad.shape == bias.shape and bias.grad.dtype == bias.dtype
+    qc, kc, vc, bc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v, bias))
+    o = ref_attention_n(qc, kc, vc, softmax_n_param=0.5, attn_bias=bc, attn_mask=None if mask is None else mask.cpu(), is_causal=causal)
+    o.backward(do.cpu().float())
+    for got, want, nm in ((out, o, "out"), (q.grad, qc.grad, "dq"), (k.grad, kc.grad, "dk"), (v.grad, vc.grad, "dv"), (bias.grad, bc.grad, "dbias")):
+        _check(got, want, dtype, f"{kind}/{nm}")
+
+
+def test_alibi_gradient_at_config4_size_without_a_dense_buffer(pkg, dev):
+    """(4,32,8192,128) with the dense ALiBi bias [H,L,S] (4.3 GB) requiring a gradient: the backward must not allocate the
+    [B,H,L,S] dS tensor (17 GB) - its extra memory stays under 6 GB - and sampled rows of dbias match the oracle."""
+    B, H, S, D, dtype = 4, 32, 8192, 128, torch.bfloat16
+    q, k, v, do = (_full(nm, (B, H, S, D), dtype, dev) for nm in ("q", "k", "v", "dout"))
+    bias = synth.alibi_bias(H, S, S, dtype, device=dev).requires_grad_()
+    mask = synth.keypad_mask(B, S, device=dev)
+    q.requires_grad_()
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, attn_bias=bias, attn_mask=mask)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out.backward(do)
+    torch.cuda.synchronize()
+    extra = torch.cuda.max_memory_allocated() - base
+    assert extra < 6 * (1 << 30), f"backward peaked {extra / 2**30:.1f} GiB above the forward state"
+    assert bias.grad.shape == bias.shape
+    # oracle on one head, a few rows: dbias[h, rows, :] = sum_b dS[b, h, rows, :]
+    h, rows = 5, torch.tensor([0, 1, 4095, 8191])
+    want = torch.zeros(len(rows), S)
+    for b in range(B):
+        qc, kc, vc = (t[b:b + 1, h:h + 1].detach().cpu().float() for t in (q, k, v))
+        bc = bias[h:h + 1].detach().cpu().float().requires_grad_()
+        o = ref_attention_n(qc, kc, vc, softmax_n_param=0.5, attn_bias=bc, attn_mask=mask[b:b + 1].cpu())
+        o.backward(do[b:b + 1, h:h + 1].cpu().float())
+        want += bc.grad[0][rows]
+    _check(bias.grad[h][rows.to(dev)], want, dtype, "alibi dbias rows")
+
+
 # ---------------------------------------------------------------- key-padding masks (MODE_KEYPAD, MODE_BIAS_KEYPAD)
 @pytest.mark.parametrize("D", [32, 64, 128])
 @pytest.mark.parametrize("causal", [False, True])
