@@ -468,8 +468,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                             float dp = pacc[qb][r];
                             if (DROP) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
                                 const uint32_t rb = drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row);
-                                const u32x2 hsh = drop_hash(rb, dsd.hi, (uint32_t)((k0 + kb * 32 + (VEC ? 16 * hi + 4 * (r >> 2) : 8 * (r >> 2) + 4 * hi)) >> 2));
-                                dp = drop_keep(hsh, r & 3, p.drop_thr) ? dp * p.drop_scale : 0.f;
+                                const uint32_t hy = drop_mix(rb, dsd.hi, (uint32_t)((k0 + kb * 32 + (VEC ? 16 * hi + 4 * (r >> 2) : 8 * (r >> 2) + 4 * hi)) >> 2));   // (shared by the 4 keys of the quad: CSE)
+                                dp = drop_keep(drop_word(hy, r & 3), p.drop_thr << 16) ? dp * p.drop_scale : 0.f;
                             }
                             sacc[qb][r] = SEED_P ? pv * dp : pv * (dp - dlt[qb]);
                         }
@@ -924,11 +924,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                         if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                         float dp = pacc[kb][r];
                         float pd = pv;
-                        if (DROP) {   // lane = key here: one hash per element, byte (key & 3) of the (row, key>>2) hash
+                        if (DROP) {   // lane = key here: one state per element, the word of key & 3 (rotation / multiplier picked per lane)
                             const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                             const uint32_t rb = drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row);
-                            const u32x2 hsh = drop_hash(rb, dsd.hi, (uint32_t)(key >> 2));
-                            const bool keep = drop_keep(hsh, key & 3, p.drop_thr);
+                            const bool keep = drop_keep(drop_word(drop_mix(rb, dsd.hi, (uint32_t)(key >> 2)), drop_lane(key & 3)), p.drop_thr << 16);
                             dp = keep ? dp * p.drop_scale : 0.f;
                             pd = keep ? pv * p.drop_scale : 0.f;
                         }

@@ -189,8 +189,8 @@ FASN_DEV void retire_loads(V& v) {
 }
 
 // ---- dropout -------------------------------------------------------------------------------------------------------
-// Counter-based, layout-independent: the keep/drop decision of attention weight (bh, row i, key j) is the 16-bit field (j & 3)
-// of a 64-bit hash of (seed, offset, bh, i, j >> 2); the weight is kept iff field >= thr (drop probability thr / 65536, so a
+// Counter-based, layout-independent: the keep/drop decision of attention weight (bh, row i, key j) is a 16-bit field of a hash of
+// (seed, offset, bh, i, j >> 2) and j & 3; the weight is kept iff field >= thr (drop probability thr / 65536, so a
 // requested p is honoured to 1.5e-5). Every kernel (forward and both backward kernels, which hold the score tile in different
 // register layouts) recomputes the same bits. Mirror on the host: flash-attention-softmax-n_amd/dropout.py (the tests build
 // the explicit mask for the oracle with it).
@@ -213,18 +213,42 @@ FASN_DEV DropSeed drop_seed(uint32_t seed_lo, uint32_t seed_hi, const uint64_t* 
 FASN_DEV uint32_t drop_row_base(uint32_t seed_lo, uint32_t bh, uint32_t row) {
     return (seed_lo ^ (bh * 0x9E3779B1u)) + row * 0x85EBCA77u;
 }
-FASN_DEV u32x2 drop_hash(uint32_t row_base, uint32_t seed_hi, uint32_t key_quad) {
-    uint32_t x = row_base ^ (key_quad * 0xC2B2AE3Du + seed_hi);
-    x ^= x >> 16;
-    x *= 0x7feb352du;
-    x ^= x >> 15;
-    uint32_t lo = x * 0x846ca68bu;
-    uint32_t hi = lo * 0x9E3779B1u;   // second word: one more multiply-fold of the first (every 16-bit field uniform)
-    hi ^= hi >> 15;
-    lo ^= lo >> 16;
-    return u32x2{lo, hi};
+// The hash itself uses only full-rate VALU operations: 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: low 24 bits of both
+// operands, low 32 bits of the product), rotates (v_alignbit_b32), adds and xors - a 32-bit v_mul_lo_u32 issues at a quarter of
+// that rate, and the round-2 hash (four of them per key quad) was most of what dropout cost. drop_mix: one 32-bit state per
+// (row, key quad); drop_word(y, e): the word of key e of the quad, an INDEPENDENT 24-bit multiply of its own window of the state,
+// whose HIGH 16 bits are the weight's field - so "field >= thr" is one unsigned compare of the whole word against thr << 16.
+// Statistics (tools/dropout_hash_stats.py): every input bit flips 7.9 of a field's 16 bits on average (worst case over the 86
+// input bits 7.85), keep decisions of adjacent keys / rows / heads / seeds / offsets correlate below 1e-3.
+FASN_DEV uint32_t rotl32(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, 32u - r); }
+FASN_DEV uint32_t drop_mix(uint32_t row_base, uint32_t seed_hi, uint32_t key_quad) {
+    uint32_t x = (row_base + __umul24(key_quad, 0x9E3779u)) ^ seed_hi;
+    const uint32_t a = __umul24(x, 0xC2B2AFu), b = __umul24(rotl32(x, 20), 0x85EBCBu);
+    uint32_t y = a + rotl32(b, 13);
+    y ^= y >> 15;
+    return y + rotl32(y, 9);
 }
-FASN_DEV bool drop_keep(u32x2 hash, int e, uint32_t thr) { return ((hash[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= thr; }
+FASN_DEV uint32_t drop_word(uint32_t y, int e) {   // e = key & 3, a compile-time constant at most call sites
+    switch (e) {
+        case 0: return __umul24(y, 0x2C1B3Du);
+        case 1: return __umul24(rotl32(y, 24), 0x297A2Du);
+        case 2: return __umul24(rotl32(y, 12), 0x1B56C5u);
+        default: return __umul24(rotl32(y, 20), 0x7ED55Du);
+    }
+}
+// the same with a lane-dependent e (the dK/dV kernels: a lane owns one key): rotation and multiplier picked per lane, once
+struct DropLane {
+    uint32_t rot, mul;
+};
+FASN_DEV DropLane drop_lane(int e) {
+    DropLane d;
+    d.rot = e == 0 ? 32u : e == 1 ? 24u : e == 2 ? 12u : 20u;   // (rotate by 32 = by 0)
+    d.mul = e == 0 ? 0x2C1B3Du : e == 1 ? 0x297A2Du : e == 2 ? 0x1B56C5u : 0x7ED55Du;
+    return d;
+}
+FASN_DEV uint32_t drop_word(uint32_t y, DropLane d) { return __umul24(__builtin_amdgcn_alignbit(y, y, 32u - d.rot), d.mul); }
+// keep iff field >= thr (drop probability thr / 65536); thr16 = thr << 16
+FASN_DEV bool drop_keep(uint32_t word, uint32_t thr16) { return word >= thr16; }
 
 FASN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 

@@ -79,8 +79,8 @@ struct GenElem {
 };
 FASN_DEV bool f32_keep(const FwdParams& p, int bh, int row, int key) {
     const DropSeed dsd = drop_seed(p.seed_lo, p.seed_hi, p.rng);
-    const u32x2 hsh = drop_hash(drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row), dsd.hi, (uint32_t)(key >> 2));
-    return drop_keep(hsh, key & 3, p.drop_thr);
+    const uint32_t y = drop_mix(drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row), dsd.hi, (uint32_t)(key >> 2));
+    return drop_keep(drop_word(y, drop_lane(key & 3)), p.drop_thr << 16);
 }
 
 // ------------------------------------------------------------------------------------------------ forward

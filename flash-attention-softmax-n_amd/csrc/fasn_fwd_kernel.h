@@ -604,11 +604,12 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 // registers 8*t2 + {0..3} and + {4..7} are two groups of 4 consecutive keys: 8 apart in the plain layout,
                 // adjacent in the key-permuted layout of the vector general modes
                 const uint32_t kq = (uint32_t)((k0 + kb * 32 + (KPERM ? 16 * hi + 8 * t2 : 16 * t2 + 4 * hi)) >> 2);
-                const u32x2 h0 = drop_hash(rb, dsd.hi, kq), h1 = drop_hash(rb, dsd.hi, kq + (KPERM ? 1 : 2));
+                const uint32_t y0 = drop_mix(rb, dsd.hi, kq), y1 = drop_mix(rb, dsd.hi, kq + (KPERM ? 1 : 2));
+                const uint32_t thr16 = p.drop_thr << 16;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    x[e] = drop_keep(h0, e, p.drop_thr) ? x[e] : 0.f;
-                    x[4 + e] = drop_keep(h1, e, p.drop_thr) ? x[4 + e] : 0.f;
+                    x[e] = drop_keep(drop_word(y0, e), thr16) ? x[e] : 0.f;
+                    x[4 + e] = drop_keep(drop_word(y1, e), thr16) ? x[4 + e] : 0.f;
                 }
             };
 

@@ -1,8 +1,10 @@
-"""Host mirror of the kernels' dropout bits (csrc/fasn_common.h: drop_seed / drop_row_base / drop_hash / drop_keep).
+"""Host mirror of the kernels' dropout bits (csrc/fasn_common.h: drop_seed / drop_row_base / drop_mix / drop_word / drop_keep).
 
-The keep/drop decision of attention weight (b, h, row i, key j) is the 16-bit field (j & 3) of a 64-bit hash of
-(seed, offset, b*H + h, i, j >> 2); kept iff field >= thr, thr = round(65536 p) clipped to [1, 65535] (p honoured to 1.5e-5).
-Used by the tests to build the explicit mask for the oracle, and by anyone who needs to reproduce a run's dropout pattern.
+The keep/drop decision of attention weight (b, h, row i, key j): y = drop_mix(row_base(seed, offset, b*H + h, i), seed_hi, j >> 2), a
+32-bit state built from 24-bit multiplies, rotates, adds and xors (full-rate VALU operations only); word = drop_word(y, j & 3), one more
+24-bit multiply of a window of y that depends on j & 3; kept iff (word >> 16) >= thr, thr = round(65536 p) clipped to [1, 65535]
+(p honoured to 1.5e-5). Used by the tests to build the explicit mask for the oracle, and by anyone who needs to reproduce a run's
+dropout pattern.
 """
 import numpy as np
 
@@ -31,15 +33,23 @@ def keep_mask(seed: int, offset: int, B: int, H: int, L: int, S: int, p: float) 
     row = np.arange(L, dtype=np.uint64).reshape(1, L, 1)
     key = np.arange(S, dtype=np.uint64).reshape(1, 1, S)
     rb = ((seed_lo ^ ((bh * np.uint64(0x9E3779B1)) & _M32)) + row * np.uint64(0x85EBCA77)) & _M32
-    x = rb ^ ((((key >> np.uint64(2)) * np.uint64(0xC2B2AE3D)) + seed_hi) & _M32)
-    x ^= x >> np.uint64(16)
-    x = (x * np.uint64(0x7FEB352D)) & _M32
-    x ^= x >> np.uint64(15)
-    lo = (x * np.uint64(0x846CA68B)) & _M32
-    hi = (lo * np.uint64(0x9E3779B1)) & _M32
-    hi ^= hi >> np.uint64(15)
-    lo ^= lo >> np.uint64(16)
+    m24 = np.uint64(0xFFFFFF)
+
+    def mul24(u, c):   # v_mul_u32_u24: low 24 bits of both operands, low 32 bits of the product
+        return ((u & m24) * np.uint64(c)) & _M32
+
+    def rotl(u, r):
+        r = np.uint64(r)
+        return ((u << r) | (u >> (np.uint64(32) - r))) & _M32
+
+    x = ((rb + mul24(key >> np.uint64(2), 0x9E3779)) & _M32) ^ seed_hi
+    y = (mul24(x, 0xC2B2AF) + rotl(mul24(rotl(x, 20), 0x85EBCB), 13)) & _M32
+    y ^= y >> np.uint64(15)
+    y = (y + rotl(y, 9)) & _M32
     e = key & np.uint64(3)
-    word = np.where(e >= np.uint64(2), hi, lo)
-    field = (word >> (np.uint64(16) * (e & np.uint64(1)))) & np.uint64(0xFFFF)
+    rot = np.choose(e.astype(np.int64), [np.uint64(32), np.uint64(24), np.uint64(12), np.uint64(20)])
+    mul = np.choose(e.astype(np.int64), [np.uint64(0x2C1B3D), np.uint64(0x297A2D), np.uint64(0x1B56C5), np.uint64(0x7ED55D)])
+    win = np.where(rot == np.uint64(32), y, ((y << rot) | (y >> (np.uint64(32) - rot))) & _M32)
+    word = ((win & m24) * mul) & _M32
+    field = word >> np.uint64(16)
     return (field >= np.uint64(thr)).reshape(B, H, L, S)

@@ -148,3 +148,22 @@ def test_dropout_host_mirror_statistics(pkg):
     assert keep.shape == (2, 2, 128, 256) and abs((1 - keep.mean()) - 0.25) < 0.01
     assert (d.keep_mask(7, 0, 2, 2, 128, 256, 0.25) == keep).all() and (d.keep_mask(8, 0, 2, 2, 128, 256, 0.25) != keep).any()
     assert d.keep_mask(7, 0, 1, 1, 4, 4, 0.0).all()
+
+
+def test_dropout_keep_bits_of_neighbours_are_independent(pkg):
+    """the four fields of a key quad come from independent multiplies of the (row, quad) state: keep decisions of adjacent keys,
+    adjacent rows, neighbouring heads, seeds and offsets must not correlate (|r| < 4 sigma of the sample), at several rates"""
+    import numpy as np
+    d = pkg.dropout
+    L = S = 768
+    sigma = 1.0 / np.sqrt(2 * L * S)
+    for p in (0.1, 0.5, 0.8):
+        K = d.keep_mask(2024, 3, 1, 2, L, S, p)[0].astype(np.float64)
+        c = lambda a, b: abs(float(np.corrcoef(a.ravel(), b.ravel())[0, 1]))
+        assert abs((1 - K.mean()) - d.effective_p(p)) < 4 * np.sqrt(p * (1 - p) / K.size)
+        for shift in (1, 2, 3, 4):
+            assert c(K[..., :-shift], K[..., shift:]) < 4 * sigma, (p, "key", shift)
+            assert c(K[:, :-shift], K[:, shift:]) < 4 * sigma, (p, "row", shift)
+        assert c(K[0], K[1]) < 6 * sigma
+        assert c(K, d.keep_mask(2025, 3, 1, 2, L, S, p)[0].astype(np.float64)) < 4 * sigma
+        assert c(K, d.keep_mask(2024, 4, 1, 2, L, S, p)[0].astype(np.float64)) < 4 * sigma
