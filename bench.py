@@ -316,7 +316,7 @@ def main():
         achieved = alg / (kernel_ms * 1e-3) / 1e12
         line["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": pmc_traffic(args.workload, args.which), "kernel_ms": kernel_ms,
+            "traffic": pmc_traffic(args.workload + ("onepass" if args.backward_plan == "one_pass" and args.which != "fwd" else ""), args.which), "kernel_ms": kernel_ms,
             "kernels": {"fwd": "fasn_fwd_kernel", "bwd": "fasn_bwd_delta + fasn_bwd_dq + fasn_bwd_dkdv", "fwdbwd": "fasn_fwd_kernel + the three backward kernels"}[args.which],
             "algorithmic_flops_per_launch": alg, "executed_flops_per_launch": exe,
             "gemm_equivalents": {"algorithmic": (GEMMS256 if D > 128 else GEMMS)[args.which][0], "executed": (GEMMS256 if D > 128 else GEMMS)[args.which][1]},

@@ -260,8 +260,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_fused_kernel(const BwdParams 
     };
 
 
-    // ---- phase X of tile tq (tile buffer TB, dS buffer dsb): S, dP, element pass, dS image; leaves P / dS fragments for phase Y
-    auto phase_x = [&](const int tq, auto TB_, const int dsb, vec8 (&pfr)[KB][2], vec8 (&dsfr)[KB][2]) __attribute__((always_inline)) -> bool {
+    // ---- one tile (tile buffer TB, dS buffer dsb): S, dP, element pass, dS image, then dV and dK
+    auto tile = [&](const int tq, auto TB_, const int dsb) __attribute__((always_inline)) {
         constexpr int tb = decltype(TB_)::value;
         const int r0 = tq * FQT;
         const char* tQ = ldsQ + tb * QTILE;
@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_fused_kernel(const BwdParams 
         }
         if (r0 + FQT > p.Sq || kw0 + KB * 32 > p.Sk) need_mask = true;
         if (!skip) {
+            vec8 pfr[KB][2], dsfr[KB][2];
             // one 32-key block at a time (S and dP accumulators of ONE block live: the dK / dV accumulators and the V fragments
             // already take 160 of the 256 registers); the Q / dO row fragments are read again for the second block
 #pragma unroll
@@ -345,6 +346,20 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_fused_kernel(const BwdParams 
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const vec8 dot = lds_read_trfrag<E, D>(tD, 16 * t2, d, lane);
+                    const vec8 qt = lds_read_trfrag<E, D>(tQ, 16 * t2, d, lane);
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        dvacc[kb][d] = E::mfma(dot, pfr[kb][t2], dvacc[kb][d]);
+                        dkacc[kb][d] = E::mfma(qt, dsfr[kb][t2], dkacc[kb][d]);
+                    }
+                }
         } else if (!causal) {
             // (plain mode: the dQ GEMM walks all 16 key steps - a wave whose keys lie past Sk clears its part of the image)
 #pragma unroll
@@ -352,30 +367,9 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_fused_kernel(const BwdParams 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) *LDS_PTR(u32x2, dsw + ws_off[g] + kb * 2048) = u32x2{0u, 0u};
         }
-        return skip;
     };
-    // ---- phase Y: dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
-    auto phase_y = [&](auto TB_, const vec8 (&pfr)[KB][2], const vec8 (&dsfr)[KB][2]) __attribute__((always_inline)) {
-        constexpr int tb = decltype(TB_)::value;
-        const char* tQ = ldsQ + tb * QTILE;
-        const char* tD = ldsDO + tb * QTILE;
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int d = 0; d < DB; ++d) {
-                const vec8 dot = lds_read_trfrag<E, D>(tD, 16 * t2, d, lane);
-                const vec8 qt = lds_read_trfrag<E, D>(tQ, 16 * t2, d, lane);
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    dvacc[kb][d] = E::mfma(dot, pfr[kb][t2], dvacc[kb][d]);
-                    dkacc[kb][d] = E::mfma(qt, dsfr[kb][t2], dkacc[kb][d]);
-                }
-            }
-    };
-
     using TB0 = std::integral_constant<int, 0>;
     using TB1 = std::integral_constant<int, 1>;
-    vec8 pfr[KB][2], dsfr[KB][2];
     // one barrier per tile: [requests for tile t+1] [dQ GEMM of tile t-1: its atomics then have the whole tile to retire] [X(t)] [Y(t)]
     auto iter = [&](const int tq, auto TB_, auto TBN_) __attribute__((always_inline)) {
         constexpr int dsb = decltype(TB_)::value;   // dS buffer = tile buffer index
@@ -385,9 +379,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_fused_kernel(const BwdParams 
         }
         if (tq > tq0 && ABL < 2) dq_gemm(tq - 1, dsb ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        const bool skip = phase_x(tq, TB_, dsb, pfr, dsfr);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!skip) phase_y(TB_, pfr, dsfr);
+        tile(tq, TB_, dsb);
         if (tq + 1 < ntq) stats_lstore(decltype(TBN_)::value);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next Q / dO tile has landed (and this tile's atomics retired)
         __syncthreads();

@@ -6,7 +6,9 @@ Mirrors, argument for argument:
   * slow_attention_n           — flash_attention_softmax_n/core/functional.py:32-93 (signature only; same kernel)
 What the reference does by materialising tensors is passed to the kernel as scalars and strides:
   n zero-padded K/V rows (flash_attn.py:66-73)        -> `softmax_n` float (real-valued n allowed)
-  q * scale/default (flash_attn.py:81-83)             -> `scale` float, folded into the exp2 argument
+  q * scale/default (flash_attn.py:81-83)             -> `scale` float; the vector kernels multiply Q (or K) by scale*log2e once, in
+                                                         registers, rounded to the operand type like the reference's pre-scaled q;
+                                                         only the element-load kernels apply it in fp32 inside the exp2 argument
   dense [B,H,L,S] mask & bias (flash_attn.py:87-113)  -> broadcast strides (0 = broadcast), `causal` flag
 PyTorch is used for device memory, streams and autograd only.
 """
@@ -429,8 +431,8 @@ def flash_attention_n(
 ) -> Tensor:
     """Fused attention with softmax_n on MI355X; drop-in for flash_attention_softmax_n.flash_attention_n.
 
-    :param query: [B, H, L, E] fp16 / bf16 device tensor (fp32 also accepted: exact-fp32 kernels, ~1/16 of the bf16 rate,
-                  no mask / bias / dropout).
+    :param query: [B, H, L, E] fp16 / bf16 device tensor, E <= 256 (fp32 also accepted: exact-fp32 kernels, ~1/16 of the bf16
+                  rate, E <= 128).
     :param key: [B, H, S, E] (or [B, S, E], shared by all heads).
     :param value: [B, H, S, Ev].
     :param softmax_n_param: n >= 0; real values allowed (the reference's SDPA path takes integers only).
@@ -439,7 +441,9 @@ def flash_attention_n(
                       the call's (seed, offset) - drawn from a per-device stream seeded by torch's CUDA generator, advanced on the
                       device so that HIP-graph replays resample - and regenerated in backward.
     :param attn_mask: bool, 4-D, broadcastable to [B, H, L, S]; True = attend.
-    :param attn_bias: additive bias [H, L, S] or broadcastable to [B, H, L, S] (e.g. ALiBi); not differentiated.
+    :param attn_bias: additive bias [H, L, S] or broadcastable to [B, H, L, S] (e.g. ALiBi). Differentiated like the reference's
+                      additive mask (core/flash_attn.py:100-113): a bias that requires grad gets dS summed over the dimensions it
+                      broadcasts - inside the kernel for batch / head broadcasts ([H,L,S], [B,1,L,S], ...: no [B,H,L,S] buffer).
     :param is_causal: bottom-right aligned causal mask (key j visible to row i iff j <= i + S - L).
     :return: [B, H, L, Ev] in query's dtype.
     Rows with no visible key and n == 0 return 0 (the reference returns NaN there).
