@@ -14,10 +14,12 @@ FASN_ABI_VERSION = 4
 FASN_BWD_ONE_PASS = 1
 FASN_DTYPE_F16, FASN_DTYPE_BF16, FASN_DTYPE_F32 = 0, 1, 2
 FASN_BIAS_NONE, FASN_BIAS_SAME, FASN_BIAS_F32 = 0, 1, 2
+FASN_PATH_NAMES = {0: "plain", 1: "key-padding", 2: "vector mask/bias", 3: "vector bias + key-padding", 4: "element-load (slow)", 5: "fp32"}
+FASN_PATH_ELEMENT = 4
 
 # every entry point include/fasn.h declares (tests check the .so exports all of them)
 EXPORTS = (
-    "fasn_abi_version", "fasn_strerror", "fasn_supported", "fasn_fwd", "fasn_fwd_workspace_bytes", "fasn_fwd_ws",
+    "fasn_abi_version", "fasn_strerror", "fasn_supported", "fasn_fwd", "fasn_fwd_path", "fasn_fwd_workspace_bytes", "fasn_fwd_ws",
     "fasn_bwd_workspace_bytes", "fasn_bwd", "fasn_rng_advance",
     "fasn_softmax_n_fwd", "fasn_softmax_n_bwd", "fasn_moments",
 )
@@ -79,6 +81,8 @@ def load():
     lib.fasn_supported.argtypes = [c_int32, c_int32, c_int32]
     lib.fasn_fwd.restype = c_int32
     lib.fasn_fwd.argtypes = [POINTER(FwdArgs), c_void_p]
+    lib.fasn_fwd_path.restype = c_int32
+    lib.fasn_fwd_path.argtypes = [POINTER(FwdArgs)]
     lib.fasn_fwd_workspace_bytes.restype = c_size_t
     lib.fasn_fwd_workspace_bytes.argtypes = [POINTER(FwdArgs)]
     lib.fasn_fwd_ws.restype = c_int32

@@ -242,6 +242,24 @@ int fasn_fwd(const fasn_fwd_args* args, fasn_stream_t stream) {
     return dispatch_fwd(p, l, (hipStream_t)stream);
 }
 
+int fasn_fwd_path(const fasn_fwd_args* args) {
+    FwdParams p;
+    FwdLaunch l;
+    const int rc = build_fwd(args, p, l);
+    if (rc) return rc;
+    if (l.dtype == FASN_DTYPE_F32) return FASN_PATH_FP32;
+    int mode = l.mode;
+    if (p.drop_thr && mode == MODE_BIAS_KEYPAD) mode = p.keypad_fallback;   // (no dropout instantiation of its own)
+    if (p.drop_thr && l.D > 128) return FASN_PATH_ELEMENT;                  // D = 256: dropout on the element-load kernels
+    switch (mode) {
+        case MODE_PLAIN: case MODE_CAUSAL: return FASN_PATH_PLAIN;
+        case MODE_KEYPAD: return FASN_PATH_KEYPAD;
+        case MODE_BIAS_KEYPAD: return FASN_PATH_BIAS_KEYPAD;
+        case MODE_GENERAL_SLOW: return FASN_PATH_ELEMENT;
+        default: return FASN_PATH_VECTOR;
+    }
+}
+
 size_t fasn_fwd_workspace_bytes(const fasn_fwd_args* args) {
     FwdParams p;
     FwdLaunch l;

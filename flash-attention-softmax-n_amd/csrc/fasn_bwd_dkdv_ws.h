@@ -355,12 +355,18 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
         u32x2 b0[4] = {}, b1[4] = {};
         if (VBIAS) bias_read(slot0, b0);
         start(0, b0, sacc);
-        if (VBIAS) bias_request(r0 + QT + 32, slot0);   // block bq + 3 = second block of the next tile
+        if (VBIAS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's values are in registers before it is requested again
+            bias_request(r0 + QT + 32, slot0);   // block bq + 3 = second block of the next tile
+        }
         if (more) tile_dma(tq + 1, decltype(BN_)::value);
         if (!skip) block(0);
         if (VBIAS) bias_read(slot1, b1);
         start(1, b1, sacc);
-        if (VBIAS) bias_request(r0 + 2 * QT, slot1);    // block bq + 4 = first block of the tile after the next
+        if (VBIAS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bias_request(r0 + 2 * QT, slot1);    // block bq + 4 = first block of the tile after the next
+        }
         if (!skip) block(1);
     };
 

@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
                     braw[kb][2 * j] = u32x2{w[0], w[1]};
                     braw[kb][2 * j + 1] = u32x2{w[2], w[3]};
                 }
-            bias_request(t + 2, par);   // (its data arrives hundreds of cycles after the reads above have left the LDS queue)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before its slot is requested again
+            bias_request(t + 2, par);
         }
         if (skip) return;
         vec8 pf[2][2];

@@ -460,6 +460,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     };
     if (LATE && ntiles > t_begin) {   // (the prologue's wait and barrier above published the first image)
         image_to_regs(mraw_c, braw_c);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         gen_dma(t_begin + 1);
     }
 
@@ -788,8 +789,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 
         if (RING == 2) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile t+1 (and its image) is in LDS, tile t+2 still in flight
-            if (LATE) {   // next tile's image -> registers, the one after it requested (its data arrives long after these reads left the LDS queue)
+            if (LATE) {   // next tile's image -> registers, the one after it requested (ordered by an explicit lgkmcnt wait: a DMA landing before a queued read would be silent corruption)
                 image_to_regs(mraw_c, braw_c);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before its slot is requested again
                 gen_dma(t + 2);
             }
             __syncthreads();

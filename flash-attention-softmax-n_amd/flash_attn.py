@@ -155,7 +155,10 @@ def _cache():
 
 
 class _Plan:
-    __slots__ = ("fwd", "fwd_ws", "bwd", "bwd_ws")
+    __slots__ = ("fwd", "fwd_ws", "bwd", "bwd_ws", "path")
+
+
+_WARNED_SLOW = set()
 
 
 def _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p, one_pass):
@@ -180,6 +183,16 @@ def _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p, one_pass):
         with torch.cuda.device(q.device):
             pl.fwd_ws = lib.fasn_fwd_workspace_bytes(pl.fwd)     # > 0: short-query / long-key shape, keys split over workgroups
             pl.bwd_ws = lib.fasn_bwd_workspace_bytes(pl.bwd)     # > 0: one-pass backward, the fp32 dQ accumulator is ours to provide
+            pl.path = lib.fasn_fwd_path(pl.fwd)
+        if pl.path == _lib.FASN_PATH_ELEMENT:   # same results, 3-5 x slower: say so once per kind of call instead of silently
+            why = (_sig(mask), _sig(bias), dropout_p > 0.0)
+            if why not in _WARNED_SLOW:
+                _WARNED_SLOW.add(why)
+                import warnings
+                warnings.warn("flash_attention_n: this call takes the element-load kernels (3-5x slower than the vector path): "
+                              "a mask / bias whose rows are not aligned vectors (fp32 bias with 16-bit q, unaligned or strided rows), "
+                              "scale <= 0 with a bias, fp16 with a very large scale, or dropout at head dim 256. "
+                              "See fasn_fwd_path in include/fasn.h.", RuntimeWarning, stacklevel=4)
         c[key] = pl
     return pl
 
@@ -404,6 +417,28 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
     else:
         out = _FlashAttentionSoftmaxN.apply(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, rng, bias_small)
     return out if Ev == dpad else out[..., :Ev]
+
+
+def kernel_path(query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[Tensor] = None, attn_bias: Optional[Tensor] = None,
+                is_causal: bool = False, dropout_p: float = 0.0, scale: Optional[float] = None) -> str:
+    """Name of the kernel family a flash_attention_n call with these arguments is routed to (fasn_fwd_path): "plain", "key-padding",
+    "vector mask/bias", "vector bias + key-padding", "element-load (slow)" or "fp32". Launches nothing."""
+    lib = _lib.load()
+    B, H, L, E = query.shape
+    S = key.shape[-2]
+    a = FwdArgs()
+    mask = None if attn_mask is None else attn_mask.expand(B, H, L, S).view(torch.uint8)
+    bias = attn_bias
+    if bias is not None:
+        bias = (bias.unsqueeze(0) if bias.dim() == 3 else bias).expand(B, H, L, S)
+    lse = torch.empty(0, device=query.device)
+    _fill_fwd(a, query, key if key.dim() == 4 else key.unsqueeze(1), value if value.dim() == 4 else value.unsqueeze(1), query, lse, mask, bias, 1.0,
+              (1.0 / sqrt(E)) if scale is None else float(scale), bool(is_causal), float(dropout_p))
+    a.lse = None
+    rc = lib.fasn_fwd_path(a)
+    if rc < 0:
+        _lib.check(rc, "fasn_fwd_path")
+    return _lib.FASN_PATH_NAMES[rc]
 
 
 def last_dropout_state():

@@ -141,6 +141,21 @@ int fasn_supported(int32_t dtype, int32_t D, int32_t Dv);
 int fasn_fwd(const fasn_fwd_args* args, fasn_stream_t stream);
 
 /*
+ * Which kernel family `args` is routed to (ABI 4; the backward of the same call takes the same family): a non-negative
+ * FASN_PATH_* value, or a negative FASN_E* code for arguments fasn_fwd would refuse. Every family gives the same results; they
+ * differ in speed. FASN_PATH_ELEMENT is the one to know about: masks / biases whose rows cannot be moved in aligned vector
+ * pieces (fp32 bias next to 16-bit q, unaligned or strided rows, key stride != 1), scale <= 0 with a bias, fp16 with
+ * scale*log2(e) > 8, and dropout at head dim 256 take per-element loads and run 3-5 x slower than the vector path. Nothing is launched. (The reference has no counterpart: its SDPA backends are picked inside torch.)
+ */
+#define FASN_PATH_PLAIN 0       /* no mask / bias (causal or not) */
+#define FASN_PATH_KEYPAD 1      /* key-padding mask as per-tile visibility bits */
+#define FASN_PATH_VECTOR 2      /* mask and / or bias through aligned vector loads / LDS images */
+#define FASN_PATH_BIAS_KEYPAD 3 /* vector bias + key-padding visibility bits */
+#define FASN_PATH_ELEMENT 4     /* per-element loads (slow) */
+#define FASN_PATH_FP32 5        /* fp32 q/k/v: exact-fp32 MFMA kernels (1/16 of the 16-bit rate) */
+int fasn_fwd_path(const fasn_fwd_args* args);
+
+/*
  * Forward with a caller-provided workspace: short-query / long-key ("decode") shapes have too few (batch, head, query block)
  * units to fill the GPU, so the keys of each unit are split over several workgroups whose partial results
  * (fp32 accumulator + running max / sum per row) are merged by a second kernel. fasn_fwd_workspace_bytes() returns the

@@ -95,6 +95,36 @@ def test_argument_validation_codes(pkg):
     assert lib.fasn_softmax_n_fwd(None, None, 1, 1, 1, 1, 0.0, 0, None) == -1
 
 
+def test_fwd_path_query(pkg):
+    """fasn_fwd_path names the kernel family of a call without launching anything (the element-load family is the slow one)"""
+    lib = pkg._lib.load()
+    assert lib.fasn_fwd_path(_args(pkg)) == 0 and lib.fasn_fwd_path(_args(pkg, causal=1)) == 0
+    assert lib.fasn_fwd_path(_args(pkg, dtype=2)) == 5
+    assert lib.fasn_fwd_path(_args(pkg, D=96, Dv=96)) == -3
+    buf = (ctypes.c_char * 4096)()
+    base = (ctypes.addressof(buf) + 15) & ~15
+
+    def with_views(mask=None, bias=None, **over):
+        a = _args(pkg, **over)
+        for name, st in (("mask", mask), ("bias", bias)):
+            if st is not None:
+                v = getattr(a, name)
+                v.ptr = base
+                for i in range(4):
+                    v.stride[i] = st[i]
+        a._keep2 = buf
+        return a
+
+    assert lib.fasn_fwd_path(with_views(mask=(8, 0, 0, 1))) == 1                                   # key padding [B,1,1,S]
+    assert lib.fasn_fwd_path(with_views(mask=(64, 64, 8, 1))) == 2                                 # dense mask
+    assert lib.fasn_fwd_path(with_views(bias=(0, 64, 8, 1), bias_dtype=1)) == 2                    # aligned 16-bit bias
+    assert lib.fasn_fwd_path(with_views(mask=(8, 0, 0, 1), bias=(0, 64, 8, 1), bias_dtype=1)) == 3
+    assert lib.fasn_fwd_path(with_views(bias=(0, 64, 8, 1), bias_dtype=2)) == 4                    # fp32 bias next to bf16 q: element loads
+    assert lib.fasn_fwd_path(with_views(bias=(0, 64, 9, 1), bias_dtype=1)) == 4                    # unaligned bias rows
+    assert lib.fasn_fwd_path(with_views(mask=(64, 64, 8, 1), dropout_p=0.1)) == 2                  # dense mask + dropout: vector kernels with dropout
+    assert lib.fasn_fwd_path(with_views(mask=(64, 64, 8, 3))) == 4                                 # key stride != 1
+
+
 def test_front_end_refuses_cpu_and_unsupported(pkg):
     q = torch.zeros(1, 1, 4, 32)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
