@@ -11,6 +11,7 @@ using namespace fasn;
 namespace fasn {
 #ifdef FASN_DEV_VARIANTS
 int g_bwd_variant = 0;
+unsigned long long* g_timeline = nullptr;
 #endif
 int launch_fwd_f32(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_f32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
@@ -145,6 +146,9 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     // push an otherwise representable operand past 65504 there: such calls take the element-load kernels, which scale in fp32.
     if (a->dtype == FASN_DTYPE_F16 && fabsf(p.c) > 8.f) l.mode = MODE_GENERAL_SLOW;
     l.variant = 0;
+#ifdef FASN_DEV_VARIANTS
+    p.timeline = g_timeline;
+#endif
     p.nsplit = 1;
     p.tps = 0;
     p.part_o = nullptr;
@@ -290,6 +294,7 @@ int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_byt
 #ifdef FASN_DEV_VARIANTS
 // developer library only (tools/libfasn_dev.so): backward A/B switch (see fasn_bwd_launch.h)
 void fasn_dev_set_bwd_variant(int v) { fasn::g_bwd_variant = v; }
+void fasn_dev_set_timeline(unsigned long long* buf) { fasn::g_timeline = buf; }
 // developer library only (tools/libfasn_dev.so): forward with an explicit tuning variant, used by tools/fasn_harness
 int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant) {
     FwdParams p;

@@ -80,8 +80,19 @@ struct FwdParams {
     int nsplit, tps;
     float* part_o;   // [B*H][nsplit][Sq][D]
     float* part_ml;  // [B*H][nsplit][Sq][2]
+#ifdef FASN_DEV_VARIANTS
+    unsigned long long* timeline;   // developer library: per workgroup {t_entry, t_loop, t_epilogue, t_end, hw_id, xcc_id, ntiles, 0} (100 MHz clock)
+#endif
 };
+#ifdef FASN_DEV_VARIANTS
+#define FASN_STAMP(slot) do { if (p.timeline != nullptr && threadIdx.x == 0) p.timeline[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FASN_STAMP(slot) do { } while (0)
+#endif
 
+#ifndef FASN_XADDR
+#define FASN_XADDR 1
+#endif
 constexpr int KT = 64;  // keys per tile
 // key-padding modes: visibility words (one per K/V tile) kept in LDS by the forward kernels: 4 KiB, Sk <= 32768. Longer key
 // sequences take the dense-mask general mode of the same mask (fasn_api.hip).
@@ -159,6 +170,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int l31 = lane & 31;
     const int hi = lane >> 5;
 
+    FASN_STAMP(0);
     int bh, qi, split = 0;
     const int wgid = VH > 1 ? (int)(blockIdx.x / VH) : (int)blockIdx.x;
     const int dv0 = VH > 1 ? (int)(blockIdx.x % VH) * DB : 0;   // first output column block of this workgroup
@@ -266,6 +278,15 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     using Set1 = std::integral_constant<int, (RING == 1)>;
     const u32x4 krw = make_rsrc_words(kbase, p.kbytes), vrw = make_rsrc_words(vbase, p.vbytes);
     const uint32_t ldsK_w = lds_addr(ldsK) + wave * 1024, ldsV_w = lds_addr(ldsV) + wave * 1024;
+    // XADDR (loops whose LDS buffer index is a run-time value, D >= 128): the swizzle is an XOR on the chunk index, so the address of
+    // k-step s / feature block d is (address of step 0 / block 0) ^ (s << 5) / ^ (d << 6) as long as the row starts are multiples of
+    // the row size (the dynamic LDS starts at 0 and every tile is a multiple of ROWB): ONE live address per operand and one v_xor
+    // per distinct (s | d) instead of a precomputed offset register per step plus two VALU per read to add the buffer offset
+    // (bias + key-padding kernel at D = 128: 228 -> 192 VGPRs, 63 VALU fewer per tile, C4 forward 4.26 -> 4.13 ms).
+    constexpr bool XADDR = RING == 2 && !UNR3 && D >= 128 && FASN_XADDR;
+    const uint32_t xk0 = lds_addr(ldsK) + l31 * ROWB + ((hi ^ swz_f<D>(l31)) << 4);
+    const uint32_t xv0 = lds_addr(ldsV) + (4 * hi + ((lane & 15) >> 2)) * ROWB +
+                         (((((lane >> 4) & 1) * 2 + ((lane & 3) >> 1)) ^ swz_f<D>(4 * hi + ((lane & 15) >> 2))) << 4) + (lane & 1) * 8;
     auto stage_direct = [&](int t, int buf) {   // RING 2: tile t -> LDS buffer buf, asynchronously (vmcnt)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -423,6 +444,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // PRIO 3 = raised priority while a wave issues its QK^T MFMAs
     if (PRIO == 2 && NW == 4 && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
 
+    FASN_STAMP(1);
     // rows of this wave: [qw0, qw0 + QB*32)
     const int wave_first_vis = qw0 + coff;                 // last visible key of the wave's first row
     const int wave_last_vis = qw0 + QB * 32 - 1 + coff;    // last visible key of the wave's last row
@@ -532,7 +554,13 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
-                        const vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
+                        vec8 kf;
+                        if (XADDR) {
+                            const u32x4 raw = *LDS_PTR(const u32x4, (uint32_t)(((xk0 + buf * TILEB) ^ (uint32_t)(s << 5)) + kb * 32 * ROWB));
+                            __builtin_memcpy(&kf, &raw, 16);
+                        } else {
+                            kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
+                        }
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
                     }
@@ -781,7 +809,16 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                     for (int d = 0; d < DB; ++d) {
-                        const vec8 vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, dv0 + d, lane);
+                        vec8 vf;
+                        if (XADDR) {
+                            const uint32_t xa = (xv0 + buf * TILEB) ^ (uint32_t)((dv0 + d) << 6);
+                            const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, (uint32_t)(xa + (kb * 32 + 16 * t2) * ROWB)));
+                            const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, (uint32_t)((xa ^ 32u) + (kb * 32 + 16 * t2 + 8) * ROWB)));
+                            const s16x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+                            __builtin_memcpy(&vf, &ab, 16);
+                        } else {
+                            vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, dv0 + d, lane);
+                        }
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
                     }
@@ -826,6 +863,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     }
     // direct-to-LDS requests issued for tiles past the end must land before this workgroup's LDS can be handed to another one
     if (RING == 2 || VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FASN_STAMP(2);
 
     if (SPLIT) {   // ---- partial result of this key range: un-normalised accumulator + (m, l) per row
         float* po = p.part_o + ((int64_t)bh * p.nsplit + split) * p.Sq * D;
@@ -879,6 +917,14 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 }
         }
     }
+#ifdef FASN_DEV_VARIANTS
+    if (p.timeline != nullptr && threadIdx.x == 0) {
+        p.timeline[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        p.timeline[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+        p.timeline[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+        p.timeline[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)ntiles;
+    }
+#endif
 }
 
 // Merge the split-K partials: m* = max_s m_s, l = sum_s l_s 2^(m_s - m*), O = sum_s acc_s 2^(m_s - m*) / l.

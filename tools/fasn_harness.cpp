@@ -12,10 +12,12 @@
 #include <string.h>
 #include <algorithm>
 #include <string>
+#include <map>
 #include <vector>
 #include "fasn.h"
 
 extern "C" int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant);
+extern "C" void fasn_dev_set_timeline(unsigned long long* buf);   // per-workgroup time stamps of the forward kernels (developer library)
 extern "C" void fasn_dev_set_bwd_variant(int v);   // 1 = one-wave dK/dV kernel where the two-wave kernel is the default
 
 #define HIP_CHECK(x)                                                                         \
@@ -537,6 +539,86 @@ static int do_bench(int argc, char** argv) {
     return 0;
 }
 
+// timeline B H Sq Sk D dtype causal [variant]: one forward launch with per-workgroup time stamps (100 MHz clock): where a workgroup's
+// life goes (prologue / tile loop / epilogue), how well the CU slots stay covered, how long the ramp and the tail are
+static int do_timeline(int argc, char** argv) {
+    if (argc < 9) return 2;
+    Problem P = mk(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]), 1.f);
+    const int variant = argc > 9 ? atoi(argv[9]) : 0;
+    if (argc > 10) P.n = (float)atof(argv[10]);
+    if (argc > 11) P.mask_kind = atoi(argv[11]);
+    if (argc > 12) P.bias_kind = atoi(argv[12]);
+    Host h;
+    make_inputs(P, h, 3);
+    Dev d;
+    dev_alloc(P, h, d);
+    fasn_bwd_args a;
+    fill_args(P, h, d, a);
+    const size_t maxwg = (size_t)P.B * P.H * ((P.Sq + 31) / 32) * 2;
+    unsigned long long* tl = nullptr;
+    HIP_CHECK(hipMalloc(&tl, maxwg * 64));
+    for (int i = 0; i < 5; ++i) fasn_fwd_variant(&a.fwd, nullptr, variant);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemset(tl, 0, maxwg * 64));
+    fasn_dev_set_timeline(tl);
+    fasn_fwd_variant(&a.fwd, nullptr, variant);
+    fasn_fwd_variant(&a.fwd, nullptr, variant);   // the second of two back-to-back launches is the one kept
+    HIP_CHECK(hipDeviceSynchronize());
+    fasn_dev_set_timeline(nullptr);
+    std::vector<unsigned long long> t(maxwg * 8);
+    HIP_CHECK(hipMemcpy(t.data(), tl, maxwg * 64, hipMemcpyDeviceToHost));
+    size_t n = 0;
+    while (n < maxwg && t[n * 8 + 3] != 0) ++n;
+    if (const char* dump = getenv("FASN_TIMELINE_DUMP")) {   // raw stamps for offline analysis (tools/timeline_gaps.py)
+        FILE* f = fopen(dump, "wb");
+        if (f) { fwrite(t.data(), 64, n, f); fclose(f); }
+    }
+    if (n == 0) { printf("no stamps\n"); return 1; }
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (size_t i = 0; i < n; ++i) { tmin = std::min(tmin, t[i * 8]); tmax = std::max(tmax, t[i * 8 + 3]); }
+    const double tick = 0.01;   // us
+    std::vector<double> pro(n), epi(n), per(n), life(n);
+    double sum_life = 0, sum_pro = 0, sum_epi = 0, sum_loop = 0, sum_tiles = 0;
+    std::map<unsigned, int> cus;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned long long* w = &t[i * 8];
+        pro[i] = (w[1] - w[0]) * tick; epi[i] = (w[3] - w[2]) * tick; life[i] = (w[3] - w[0]) * tick;
+        per[i] = w[6] ? (w[2] - w[1]) * tick / (double)w[6] : 0;
+        sum_life += life[i]; sum_pro += pro[i]; sum_epi += epi[i]; sum_loop += (w[2] - w[1]) * tick; sum_tiles += (double)w[6];
+        const unsigned hw = (unsigned)w[4], xcc = (unsigned)w[5] & 15;
+        cus[(xcc << 16) | (hw & 0xff00) | ((hw >> 13) & 7) << 4 | ((hw >> 12) & 1)]++;   // (xcc, cu, se, sh)
+    }
+    auto pct = [&](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+    const double span = (tmax - tmin) * tick;
+    printf("timeline B%d H%d Sq%d Sk%d D%d causal%d variant%d: %zu workgroups on %zu CUs, span %.1f us\n", P.B, P.H, P.Sq, P.Sk, P.D, P.causal, variant, n, cus.size(), span);
+    printf("  per workgroup: prologue mean %.2f us (p10 %.2f p50 %.2f p90 %.2f)   epilogue mean %.2f (p50 %.2f p90 %.2f)   tile mean %.3f us (p10 %.3f p50 %.3f p90 %.3f)\n",
+           sum_pro / n, pct(pro, .1), pct(pro, .5), pct(pro, .9), sum_epi / n, pct(epi, .5), pct(epi, .9), sum_loop / sum_tiles, pct(per, .1), pct(per, .5), pct(per, .9));
+    printf("  sum of workgroup lifetimes %.0f us = %.2f resident workgroups per CU over the span; prologue %.1f%% loop %.1f%% epilogue %.1f%% of the lifetimes\n",
+           sum_life, sum_life / span / cus.size(), 100 * sum_pro / sum_life, 100 * sum_loop / sum_life, 100 * sum_epi / sum_life);
+    // concurrency profile: resident workgroups in 20 slices of the span
+    printf("  resident workgroups / CU per 5%% slice of the span:");
+    for (int sl = 0; sl < 20; ++sl) {
+        const double a0 = tmin * tick + span * sl / 20, a1 = a0 + span / 20;
+        double acc = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const double s0 = std::max(a0, t[i * 8] * tick), s1 = std::min(a1, t[i * 8 + 3] * tick);
+            if (s1 > s0) acc += s1 - s0;
+        }
+        printf(" %.2f", acc / (span / 20) / cus.size());
+    }
+    printf("\n");
+    // start-to-start: first start of each workgroup relative to the kernel's first stamp
+    std::vector<double> st(n);
+    for (size_t i = 0; i < n; ++i) st[i] = (t[i * 8] - tmin) * tick;
+    std::sort(st.begin(), st.end());
+    const size_t first = std::min(n, cus.size() * 3);
+    printf("  workgroup starts: #%zu at %.1f us, #%zu at %.1f us; last start %.1f us; last end %.1f us\n", cus.size(), st[std::min(n, cus.size()) - 1], first, st[first - 1], st[n - 1], span);
+    fflush(stdout);
+    hipFree(tl);
+    dev_free(d);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) {
         fprintf(stderr, "usage: %s probe | test [variant] [quick] | bench ...\n", argv[0]);
@@ -549,5 +631,6 @@ int main(int argc, char** argv) {
         return do_test(argc > 2 ? atoi(argv[2]) : 0, argc > 3 && atoi(argv[3]) != 0);
     }
     if (cmd == "bench") return do_bench(argc, argv);
+    if (cmd == "timeline") return do_timeline(argc, argv);
     return 2;
 }
