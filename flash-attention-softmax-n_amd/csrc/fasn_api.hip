@@ -12,6 +12,7 @@ namespace fasn {
 #ifdef FASN_DEV_VARIANTS
 int g_bwd_variant = 0;
 unsigned long long* g_timeline = nullptr;
+int g_pair_mode = -1;
 #endif
 int launch_fwd_f32(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_f32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
@@ -149,6 +150,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
 #ifdef FASN_DEV_VARIANTS
     p.timeline = g_timeline;
 #endif
+    p.pair = 0;   // set per launch (paired causal blocks, fasn_launch.h)
     p.nsplit = 1;
     p.tps = 0;
     p.part_o = nullptr;
@@ -295,6 +297,7 @@ int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_byt
 // developer library only (tools/libfasn_dev.so): backward A/B switch (see fasn_bwd_launch.h)
 void fasn_dev_set_bwd_variant(int v) { fasn::g_bwd_variant = v; }
 void fasn_dev_set_timeline(unsigned long long* buf) { fasn::g_timeline = buf; }
+void fasn_dev_set_pair_mode(int v) { fasn::g_pair_mode = v; }
 // developer library only (tools/libfasn_dev.so): forward with an explicit tuning variant, used by tools/fasn_harness
 int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant) {
     FwdParams p;

@@ -156,9 +156,14 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
 
     int bh, qi;
-    block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
     const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
-    const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
+    // paired causal launch (see fasn_fwd_kernel.h): query block nblk-1-r, then block r, so that every workgroup walks the same number of tiles
+    constexpr bool PAIRABLE = MODE == MODE_CAUSAL && !DROP;
+    block_to_work(blockIdx.x, p.B * p.H, (PAIRABLE && p.pair) ? (bp.nblk + 1) / 2 : bp.nblk, bh, qi);
+    const int npass = (PAIRABLE && p.pair && qi != bp.nblk - 1 - qi) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+    if (pass) __syncthreads();   // the first block's last tile has been read by every wave before the buffers are refilled
+    const int qblk = causal ? (pass == 0 ? bp.nblk - 1 - qi : qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * BM;
     const int qw0 = q0 + wave * (QB * 32);
@@ -559,6 +564,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                 }
         }
     }
+    }   // pass
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -595,9 +601,15 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
 
     const int kvg = GQA ? p.kvg : 1;
     const int Hkv = p.H / kvg;
-    int bhk, kblk;
+    int bhk, kblk0;
     const int d0 = DH > 1 ? (int)(blockIdx.x % DH) * DB : 0;   // first feature block of this workgroup
-    block_to_work(DH > 1 ? (int)(blockIdx.x / DH) : (int)blockIdx.x, p.B * Hkv, bp.nblk, bhk, kblk);
+    // paired causal launch (see fasn_fwd_kernel.h): key block r (seen by the most query rows), then block nblk-1-r
+    constexpr bool PAIRABLE = MODE == MODE_CAUSAL && !DROP && !GQA && DH == 1;
+    block_to_work(DH > 1 ? (int)(blockIdx.x / DH) : (int)blockIdx.x, p.B * Hkv, (PAIRABLE && p.pair) ? (bp.nblk + 1) / 2 : bp.nblk, bhk, kblk0);
+    const int npass = (PAIRABLE && p.pair && kblk0 != bp.nblk - 1 - kblk0) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+    if (pass) __syncthreads();   // the first block's last tile has been read by every wave before the buffers are refilled
+    const int kblk = pass == 0 ? kblk0 : bp.nblk - 1 - kblk0;
     const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
     const int b = bhk / Hkv, hk = bhk % Hkv;
     const int kw0 = kblk * BN + wave * (KB * 32);  // first key of this wave
@@ -1013,6 +1025,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 }
         }
     }
+    }   // pass
 }
 
 }  // namespace fasn

@@ -52,7 +52,10 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         p.nblk = (p.f.Sq + BM - 1) / BM;
         constexpr auto kern = &fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q, DROP>;
         ensure_smem<kern>(smem);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
+        // causal: block r and block nblk-1-r in one workgroup (equal workgroups for the in-order dispatcher, see fasn_fwd_kernel.h)
+        p.f.pair = (MODE == MODE_CAUSAL && !DROP && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * OCC_Q)) ? 1 : 0;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
+        p.f.pair = 0;
     }
     if constexpr (WS != 0 && DROP == 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
         if (!(FASN_BWD_VARIANT & 1)) {   // dK, dV: two cooperating waves per key block
@@ -81,7 +84,8 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         } else {
             constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 0, DH>;
             ensure_smem<kern>(smem);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh * DH)), dim3(256), smem, s, p);
+            p.f.pair = (MODE == MODE_CAUSAL && !DROP && DH == 1 && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * OCC_K)) ? 1 : 0;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh * DH)), dim3(256), smem, s, p);
         }
     }
     return launch_rc();

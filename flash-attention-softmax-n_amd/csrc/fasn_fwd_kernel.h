@@ -78,6 +78,7 @@ struct FwdParams {
     int kvg;        // query heads per K/V head (grouped-query attention); 1 = one K/V head per query head
     int keypad_fallback;   // MODE_KEYPAD launches: the general mode (vector or element-load) the same mask would otherwise take
     int nsplit, tps;
+    int pair;       // causal (MODE_CAUSAL kernels): one workgroup takes query block r AND block nqblk-1-r of its head, one after the other
     float* part_o;   // [B*H][nsplit][Sq][D]
     float* part_ml;  // [B*H][nsplit][Sq][2]
 #ifdef FASN_DEV_VARIANTS
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // a ballot turns the 64 bytes into a wave-uniform bit word; tiles with all keys visible run as plain tiles, tiles with none
     // are skipped, only the boundary tiles start their hidden scores at -inf. Key-padded batches cost what unpadded ones do.
     constexpr bool KP = mode_has_keypad(MODE);
+    constexpr bool PAIRABLE = MODE == MODE_CAUSAL && !SPLIT && VH == 1 && !DROP;
     if (SPLIT) {
         int blk;
         block_to_work(wgid, p.B * p.H, p.nqblk * p.nsplit, bh, blk);
@@ -195,11 +197,21 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         const int bb = j % p.B, rest = j / p.B;
         qi = rest % p.nqblk;
         bh = bb * p.H + (rest / p.nqblk) * 8 + xcd;
+    } else if (PAIRABLE && p.pair) {
+        block_to_work(wgid, p.B * p.H, (p.nqblk + 1) / 2, bh, qi);
     } else {
         block_to_work(wgid, p.B * p.H, p.nqblk, bh, qi);
     }
+    // Paired causal launch: the workgroup dispatcher hands workgroups out IN ORDER and waits for the CU whose turn it is (tools/
+    // fasn_harness timeline: with 80..128-tile workgroups next to each other a CU idles until the longest of its round is done), so
+    // unequal causal blocks leave 7 % of the workgroup slots empty even when sorted by weight. Block r and block nqblk-1-r together
+    // always walk nqblk + 1 tiles: every workgroup of a paired launch costs the same. Used when the launch is many rounds long
+    // (equal workgroups quantise the last round).
+    const int npass = (PAIRABLE && p.pair && qi != p.nqblk - 1 - qi) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+    if (PAIRABLE && pass) __syncthreads();
     // causal: heaviest (last) query blocks first
-    const int qblk = (MODE != MODE_PLAIN && p.causal) ? (p.nqblk - 1 - qi) : qi;
+    const int qblk = (MODE != MODE_PLAIN && p.causal) ? (pass == 0 ? p.nqblk - 1 - qi : qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * BM;
     const int qw0 = q0 + wave * (QB * 32);  // first row of this wave
@@ -922,9 +934,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         p.timeline[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
         p.timeline[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
         p.timeline[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
-        p.timeline[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)ntiles;
+        p.timeline[(size_t)blockIdx.x * 8 + 6] = (pass ? p.timeline[(size_t)blockIdx.x * 8 + 6] : 0ull) + (unsigned long long)ntiles;
     }
 #endif
+    }   // pass
 }
 
 // Merge the split-K partials: m* = max_s m_s, l = sum_s l_s 2^(m_s - m*), O = sum_s acc_s 2^(m_s - m*) / l.

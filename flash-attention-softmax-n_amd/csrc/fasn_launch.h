@@ -44,6 +44,13 @@ constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB) {
 }
 
 // one instantiation of the forward kernel: NW waves x QB 32-row blocks per wave, staging scheme RING, accumulator seeding SEED
+constexpr int kPairRounds = 2;   // (measured: C3, 5.3 rounds of single blocks, 0.350 -> 0.335 ms paired; C5, 43 rounds, 2.45 -> 2.39; (4,32,8192,128) 2.19 -> 2.14)
+#ifdef FASN_DEV_VARIANTS
+extern int g_pair_mode;   // developer library: -1 = shipped rule, 0 = never pair, 1 = always pair (tools/fasn_harness, env FASN_PAIR)
+inline bool pair_wanted(long blocks, long slots) { return g_pair_mode < 0 ? blocks >= kPairRounds * slots : g_pair_mode != 0; }
+#else
+inline bool pair_wanted(long blocks, long slots) { return blocks >= kPairRounds * slots; }
+#endif
 template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int RING = 0, int SEED = 0, int DROP = 0, int VH = 1>
 int launch_fwd_one(FwdParams p, hipStream_t s) {
     constexpr int BM = NW * QB * 32;
@@ -51,7 +58,15 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
     p.nqblk = (p.Sq + BM - 1) / BM;
     constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, 0, DROP, RING, 0, SEED, VH>;
     ensure_smem<kern>(smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H * VH)), dim3(NW * 64), smem, s, p);
+    // causal: pair block r with block nqblk-1-r in one workgroup (equal workgroups, see the kernel) when the single blocks fill the
+    // chip's workgroup slots at least kPairRounds times; smaller launches keep single blocks, heaviest first
+    int blocks = p.nqblk;
+    p.pair = 0;
+    if (MODE == MODE_CAUSAL && VH == 1 && !DROP && p.nqblk > 1 && pair_wanted((long)p.nqblk * p.B * p.H, 256L * OCC)) {
+        p.pair = 1;
+        blocks = (p.nqblk + 1) / 2;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * p.B * p.H * VH)), dim3(NW * 64), smem, s, p);
     return launch_rc();
 }
 

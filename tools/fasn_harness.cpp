@@ -17,6 +17,7 @@
 #include "fasn.h"
 
 extern "C" int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant);
+extern "C" void fasn_dev_set_pair_mode(int v);   // causal block pairing: -1 shipped rule, 0 off, 1 on (env FASN_PAIR)
 extern "C" void fasn_dev_set_timeline(unsigned long long* buf);   // per-workgroup time stamps of the forward kernels (developer library)
 extern "C" void fasn_dev_set_bwd_variant(int v);   // 1 = one-wave dK/dV kernel where the two-wave kernel is the default
 
@@ -624,6 +625,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "usage: %s probe | test [variant] [quick] | bench ...\n", argv[0]);
         return 2;
     }
+    if (const char* pm = getenv("FASN_PAIR")) fasn_dev_set_pair_mode(atoi(pm));
     std::string cmd = argv[1];
     if (cmd == "probe") return do_probe();
     if (cmd == "test") {
