@@ -42,6 +42,30 @@ def _oracle_fwd_bwd(q, k, v, do, **kw):
     return o, qc.grad, kc.grad, vc.grad
 
 
+# ---------------------------------------------------------------- paired causal launches
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("L,S", [(1152, 1152), (1152, 1408), (640, 640)])
+def test_causal_launches_that_pair_their_blocks(pkg, dev, L, S, dtype):
+    """Causal launches with at least two rounds of workgroups put block r and block nblk-1-r of a head into one workgroup
+    (csrc/fasn_launch.h: forward, dQ and dK/dV). Odd block counts (9 and 5 x 128 rows: the middle block runs alone), L != S
+    (bottom-right aligned diagonal) and every head compared with the oracle on a few (batch, head) slices, all rows finite."""
+    B, H, D = 13, 32, 64   # 416 heads x 9 (5) blocks >= 2 x 768 (512) workgroup slots
+    q = _rand((B, H, L, D), dtype, dev, 11).requires_grad_()
+    k, v = (_rand((B, H, S, D), dtype, dev, s).requires_grad_() for s in (12, 13))
+    do = _rand((B, H, L, D), dtype, dev, 14, std=1.0)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, is_causal=True)
+    out.backward(do)
+    for t in (out, q.grad, k.grad, v.grad):
+        assert torch.isfinite(t).all()
+    for b, h in ((0, 0), (5, 17), (12, 31)):
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        o, dq, dk, dv = _oracle_fwd_bwd(q[sl], k[sl], v[sl], do[sl], softmax_n_param=1.0, is_causal=True)
+        _check(out[sl], o, dtype, f"out[{b},{h}]")
+        _check(q.grad[sl], dq, dtype, f"dq[{b},{h}]")
+        _check(k.grad[sl], dk, dtype, f"dk[{b},{h}]")
+        _check(v.grad[sl], dv, dtype, f"dv[{b},{h}]")
+
+
 # ---------------------------------------------------------------- the reference's own GPU test, same grid
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("is_causal", [False, True])
