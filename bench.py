@@ -271,7 +271,12 @@ def main():
         # The roofline measurement (dominant kernels, back to back) runs FIRST: it is part of what this script reports anyway,
         # and it leaves the device at its sustained clocks, so that the W warm-up + K timed steps below measure the steady
         # state a long-running job sees rather than the power ramp of a cold GPU (+5 % on the first ~20 launches).
-        raw = {"fwd": lambda: lib.fasn_fwd(fargs, stream), "bwd": lambda: lib.fasn_bwd(bargs, stream)}
+        # (the forward goes through fasn_fwd_ws with the workspace it asks for, like the front end does: split-K partials or the
+        # work counters of the persistent bias launches)
+        fws_bytes = lib.fasn_fwd_workspace_bytes(fargs)
+        fws = torch.empty(max(fws_bytes, 16), dtype=torch.uint8, device=dev)
+        raw = {"fwd": (lambda: lib.fasn_fwd_ws(fargs, fws.data_ptr(), fws_bytes, stream)) if fws_bytes else (lambda: lib.fasn_fwd(fargs, stream)),
+               "bwd": lambda: lib.fasn_bwd(bargs, stream)}
         if args.which in raw:
             kernel_ms = kernel_time(raw[args.which], max(200 if args.which == "fwd" else 60, args.steps))
         else:

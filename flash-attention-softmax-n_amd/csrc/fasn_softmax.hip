@@ -240,16 +240,115 @@ __global__ void __launch_bounds__(256) softmax_n_bwd_wave_kernel(const char* y, 
     }
 }
 
+
+// ---- one WORKGROUP per row, 16-byte loads, the row in registers (NV vectors per thread: rows of up to 256 * NV vectors = 32768
+// 16-bit elements at NV = 16): what the wave kernels do, for rows too long for one wave. One read and one write of every element
+// (the element-load kernels above read a long row three times, two bytes per lane: 1.4 TB/s at [4096 x 32768]).
+template <int DT, int NV>
+__global__ void __launch_bounds__(256) softmax_n_fwd_block_kernel(const char* x, char* y, int64_t rows, int cols, int64_t xs_bytes, int64_t ys_bytes, float n) {
+    constexpr int EPV = VecIO<DT>::EPV;
+    __shared__ float red[4];
+    const int nvec = cols / EPV;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * xs_bytes);
+        u32x4 raw[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = (int)threadIdx.x + 256 * i;
+            raw[i] = vi < nvec ? xr[vi] : u32x4{0u, 0u, 0u, 0u};
+        }
+        float v[NV][EPV];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            VecIO<DT>::unpack(raw[i], v[i]);
+            if ((int)threadIdx.x + 256 * i < nvec) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) mx = fmaxf(mx, v[i][e]);
+            }
+        }
+        mx = block_reduce<true>(mx, red);
+        if (n > 0.f) mx = fmaxf(mx, 0.f);
+        if (mx == -INFINITY) mx = 0.f;  // all -inf, n == 0: exp(-inf)/0 -> NaN like the reference
+        const float mx2 = mx * kLog2e;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bool ok = (int)threadIdx.x + 256 * i < nvec;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                v[i][e] = ok ? fast_exp2(__builtin_fmaf(v[i][e], kLog2e, -mx2)) : 0.f;
+                sum += v[i][e];
+            }
+        }
+        sum = block_reduce<false>(sum, red);
+        const float inv = 1.0f / (n * __expf(-mx) + sum);
+        u32x4* yr = reinterpret_cast<u32x4*>(y + row * ys_bytes);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = (int)threadIdx.x + 256 * i;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) v[i][e] *= inv;
+            if (vi < nvec) yr[vi] = VecIO<DT>::pack(v[i]);
+        }
+    }
+}
+
+template <int DT, int NV>
+__global__ void __launch_bounds__(256) softmax_n_bwd_block_kernel(const char* y, const char* dy, char* dx, int64_t rows, int cols, int64_t ys_bytes, int64_t dys_bytes, int64_t dxs_bytes) {
+    constexpr int EPV = VecIO<DT>::EPV;
+    __shared__ float red[4];
+    const int nvec = cols / EPV;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const u32x4* yr = reinterpret_cast<const u32x4*>(y + row * ys_bytes);
+        const u32x4* gr = reinterpret_cast<const u32x4*>(dy + row * dys_bytes);
+        u32x4 yraw[NV], graw[NV];   // kept packed: unpacked once for the dot product and once for the result
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = (int)threadIdx.x + 256 * i;
+            const bool ok = vi < nvec;
+            yraw[i] = ok ? yr[vi] : u32x4{0u, 0u, 0u, 0u};
+            graw[i] = ok ? gr[vi] : u32x4{0u, 0u, 0u, 0u};
+            float yv[EPV], gv[EPV];
+            VecIO<DT>::unpack(yraw[i], yv);
+            VecIO<DT>::unpack(graw[i], gv);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) dot = __builtin_fmaf(yv[e], gv[e], dot);
+        }
+        dot = block_reduce<false>(dot, red);
+        u32x4* xr = reinterpret_cast<u32x4*>(dx + row * dxs_bytes);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = (int)threadIdx.x + 256 * i;
+            float yv[EPV], gv[EPV];
+            VecIO<DT>::unpack(yraw[i], yv);
+            VecIO<DT>::unpack(graw[i], gv);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) yv[e] *= gv[e] - dot;
+            if (vi < nvec) xr[vi] = VecIO<DT>::pack(yv);
+        }
+    }
+}
+
 template <int DT>
 static bool launch_fwd_wave(const void* x, void* y, int64_t rows, int64_t cols, int64_t xs, int64_t ys, float n, hipStream_t s) {
     constexpr int esz = DT == FASN_DTYPE_F32 ? 4 : 2, EPV = VecIO<DT>::EPV;
     if (cols % EPV || (xs * esz) % 16 || (ys * esz) % 16 || reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(y) % 16) return false;
     const int64_t nvec = cols / EPV;
-    if (nvec > 64 * 16) return false;
-    const int64_t blocks = (rows + 3) / 4;
-    const dim3 grid((unsigned)(blocks < kMaxRowGrid ? blocks : kMaxRowGrid));
+    if (nvec > 256 * 16) return false;
     const char* xp = (const char*)x;
     char* yp = (char*)y;
+    if (nvec > 64 * 16) {   // too long for one wave's registers: one workgroup per row
+        const dim3 bgrid((unsigned)(rows < kMaxRowGrid ? rows : kMaxRowGrid));
+#define FASN_SM_FWDB(NV) hipLaunchKernelGGL((softmax_n_fwd_block_kernel<DT, NV>), bgrid, dim3(256), 0, s, xp, yp, rows, (int)cols, xs * esz, ys * esz, n)
+        if (nvec <= 256 * 8) FASN_SM_FWDB(8);
+        else FASN_SM_FWDB(16);
+#undef FASN_SM_FWDB
+        return true;
+    }
+    const int64_t blocks = (rows + 3) / 4;
+    const dim3 grid((unsigned)(blocks < kMaxRowGrid ? blocks : kMaxRowGrid));
 #define FASN_SM_FWD(NV) hipLaunchKernelGGL((softmax_n_fwd_wave_kernel<DT, NV>), grid, dim3(256), 0, s, xp, yp, rows, (int)cols, xs * esz, ys * esz, n)
     if (nvec <= 64 * 2) FASN_SM_FWD(2);
     else if (nvec <= 64 * 4) FASN_SM_FWD(4);
@@ -265,11 +364,20 @@ static bool launch_bwd_wave(const void* y, const void* dy, void* dx, int64_t row
         reinterpret_cast<uintptr_t>(dx) % 16)
         return false;
     const int64_t nvec = cols / EPV;
-    if (nvec > 64 * 8) return false;
-    const int64_t blocks = (rows + 3) / 4;
-    const dim3 grid((unsigned)(blocks < kMaxRowGrid ? blocks : kMaxRowGrid));
+    if (nvec > 256 * 16) return false;
     const char *yp = (const char*)y, *gp = (const char*)dy;
     char* xp = (char*)dx;
+    if (nvec > 64 * 8) {   // too long for one wave's registers: one workgroup per row
+        const dim3 bgrid((unsigned)(rows < kMaxRowGrid ? rows : kMaxRowGrid));
+#define FASN_SM_BWDB(NV) hipLaunchKernelGGL((softmax_n_bwd_block_kernel<DT, NV>), bgrid, dim3(256), 0, s, yp, gp, xp, rows, (int)cols, ys * esz, dys * esz, dxs * esz)
+        if (nvec <= 256 * 4) FASN_SM_BWDB(4);
+        else if (nvec <= 256 * 8) FASN_SM_BWDB(8);
+        else FASN_SM_BWDB(16);
+#undef FASN_SM_BWDB
+        return true;
+    }
+    const int64_t blocks = (rows + 3) / 4;
+    const dim3 grid((unsigned)(blocks < kMaxRowGrid ? blocks : kMaxRowGrid));
 #define FASN_SM_BWD(NV) hipLaunchKernelGGL((softmax_n_bwd_wave_kernel<DT, NV>), grid, dim3(256), 0, s, yp, gp, xp, rows, (int)cols, ys * esz, dys * esz, dxs * esz)
     if (nvec <= 64 * 2) FASN_SM_BWD(2);
     else if (nvec <= 64 * 4) FASN_SM_BWD(4);

@@ -828,6 +828,18 @@ def test_softmax_n_kernel(pkg, dev, golden_dir, n, dtype):
     assert torch.allclose(z.transpose(1, 2).float(), y.detach().float(), atol=1e-6)
     w = synth.counter_normal((3, 5000), 5, std=3.0, dtype=dtype, device=dev)  # cols > register cache
     assert torch.allclose(pkg.softmax_n(w, n=n).float().cpu(), ref_softmax_n(w.cpu().float(), n=n), atol=tol, rtol=tol)
+    # rows too long for one wave's registers: one workgroup per row, forward and backward (12288 and 32768 take the 16-byte kernels,
+    # 40000 the element-load kernels)
+    for cols in (12288, 32768, 40000):
+        xl = synth.counter_normal((5, cols), 6, std=2.0, dtype=dtype, device=dev).requires_grad_()
+        dl = synth.counter_normal((5, cols), 7, std=1.0, dtype=dtype, device=dev)
+        yl = pkg.softmax_n(xl, n=n)
+        yl.backward(dl)
+        xr = xl.detach().cpu().float().requires_grad_()
+        yr = ref_softmax_n(xr, n=n)
+        yr.backward(dl.cpu().float())
+        assert (yl.detach().cpu().float() - yr.detach()).abs().max().item() <= tol * max(yr.abs().max().item(), 1e-3) + 1e-7, cols
+        assert (xl.grad.cpu().float() - xr.grad).abs().max().item() <= 4 * tol * max(xr.grad.abs().max().item(), 1e-3) + 1e-7, cols
 
 
 # ---------------------------------------------------------------- randomized sweep
