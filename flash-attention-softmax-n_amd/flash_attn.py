@@ -396,7 +396,7 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
     if bias is None:
         bias_small = False
     rng = _next_rng_state(query.device) if dropout_p > 0.0 else None
-    _attention.last_rng_state = rng
+    _TLS.last_rng_state = rng   # per thread: what last_dropout_state() / last_rng_state() report
     Hkv = k.shape[1]
     if L == 1 and Hkv != H and dropout_p == 0.0:
         # grouped-query decode: the G query heads of a group become G query ROWS of one problem per K/V head, so each K/V head
@@ -441,10 +441,16 @@ def kernel_path(query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[T
     return _lib.FASN_PATH_NAMES[rc]
 
 
+def last_rng_state():
+    """What the calling thread's most recent flash_attention_n call used as its dropout state: None (no dropout), a (seed, offset)
+    tuple (eager calls: passed by value) or the device tensor {seed, offset} a HIP-graph capture reads at every replay."""
+    return getattr(_TLS, "last_rng_state", None)
+
+
 def last_dropout_state():
     """(seed, offset) of the most recent dropout call as Python ints (one device read), for dropout.keep_mask; None if that call
     had dropout_p == 0. Test / reproduction helper."""
-    t = getattr(_attention, "last_rng_state", None)
+    t = getattr(_TLS, "last_rng_state", None)
     if t is None:
         return None
     if isinstance(t, tuple):

@@ -699,7 +699,7 @@ def test_dropout_stream_follows_the_torch_generator_and_resamples_in_graph_repla
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         go = pkg.flash_attention_n(sq, sk, sv, softmax_n_param=1.0, dropout_p=p)
-        state_t = pkg.flash_attn._attention.last_rng_state
+        state_t = pkg.flash_attn.last_rng_state()
         go.backward(do)
     outs, states = [], []
     for _ in range(3):
