@@ -72,7 +72,59 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     int bhk, kblk;
     if (VBIAS && p.batch_inner && (Hkv & 7) == 0) {
         // per XCD: (head, key block, batch) with the batch fastest: the B workgroups that read the same bias columns run together
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int xcd = blockIdx.x & 7;
+        int j = blockIdx.x >> 3;
+        // Key-padded batch: a workgroup whose 128 keys are all padding has nothing to do, but under the in-order dispatcher its CU
+        // still waits a whole round for its next turn (tools/fasn_harness timeline) - skipping 22 % of C4's key blocks bought nothing.
+        // Every workgroup therefore reads the whole key-padding mask once (B x Sk bytes from L2, a few microseconds against its
+        // milliseconds of work), marks the (batch, key block) pairs with a visible key, and takes the j-th VISIBLE pair of its
+        // XCD's list (same order, batch fastest): the workgroups without work are the LAST ids of the launch and leave in whole rounds.
+        constexpr int kCompactBytes = 64 * 1024, kCompactBlocks = 2048;
+#ifdef FASN_NO_COMPACT
+        const bool compact = false;
+#else
+        const bool compact = KPD && !GQA && p.mask != nullptr && p.ms[1] == 0 && (int64_t)p.B * p.Sk <= kCompactBytes &&
+                             p.B * bp.nblk <= kCompactBlocks && (p.Sk & 15) == 0 && (p.ms[0] & 15) == 0 &&
+                             (reinterpret_cast<uintptr_t>(p.mask) & 15) == 0;
+#endif
+        if (compact) {
+            uint8_t* const vis = reinterpret_cast<uint8_t*>(smem);   // [B][nblk] (the Q buffers are not in use yet)
+            for (int i = threadIdx.x; i < p.B * bp.nblk; i += 512) vis[i] = 0;
+            __syncthreads();
+            const int cpr = p.Sk >> 4;   // 16-byte chunks per mask row
+            for (int c = threadIdx.x; c < p.B * cpr; c += 512) {
+                const int bb = c / cpr, k16 = c - bb * cpr;
+                const u32x4 w = *reinterpret_cast<const u32x4*>(p.mask + (int64_t)bb * p.ms[0] + 16 * k16);
+                if ((w[0] | w[1] | w[2] | w[3]) != 0u) vis[bb * bp.nblk + (k16 >> 3)] = 1;   // 128 keys = 8 chunks
+            }
+            __syncthreads();
+            int per_head = 0;
+            for (int i = 0; i < p.B * bp.nblk; ++i) per_head += vis[i];
+            // visible pairs first (hpx heads x per_head of them), then the pairs without a visible key: those workgroups only write
+            // their zero dK / dV rows
+            const int hpx = Hkv >> 3, all_pairs = p.B * bp.nblk;
+            const bool want = j < hpx * per_head;
+            const int per = want ? per_head : all_pairs - per_head;
+            const int jj = want ? j : j - hpx * per_head;
+            const int hd = jj / per;
+            int r = jj - hd * per, kb = 0, bsel = -1;
+            for (; kb < bp.nblk && bsel < 0; ++kb) {
+                int cnt = 0;
+                for (int bb = 0; bb < p.B; ++bb) cnt += (vis[bb * bp.nblk + kb] != 0) == want;
+                if (r < cnt) {
+                    for (int bb = 0; bb < p.B; ++bb) {
+                        if (((vis[bb * bp.nblk + kb] != 0) == want) && r-- == 0) {
+                            bsel = bb;
+                            break;
+                        }
+                    }
+                } else {
+                    r -= cnt;
+                }
+            }
+            __syncthreads();   // everybody has read `vis` before the first tile lands in the same LDS
+            j = (hd * bp.nblk + (kb - 1)) * p.B + bsel;
+        }
         const int bb = j % p.B, rest = j / p.B;
         kblk = rest % bp.nblk;
         bhk = bb * Hkv + (rest / bp.nblk) * 8 + xcd;

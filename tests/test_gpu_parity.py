@@ -1066,6 +1066,37 @@ def test_alibi_gradient_at_config4_size_without_a_dense_buffer(pkg, dev):
     _check(bias.grad[h][rows.to(dev)], want, dtype, "alibi dbias rows")
 
 
+# ---------------------------------------------------------------- dK/dV key-block compaction (csrc/fasn_bwd_dkdv_ws.h)
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_padded_key_blocks_are_compacted_in_the_two_wave_dkdv_kernel(pkg, dev, dtype, causal):
+    """D = 128, a bias broadcast over the batch and a [B,1,1,S] key-padding mask with whole 128-key blocks hidden (at the end, in the
+    middle, a batch element with a single visible key, one with none hidden): the dK/dV workgroups take the j-th (batch, key block)
+    pair WITH a visible key, the hidden pairs go to the last workgroup ids and only write zeros. Every dk / dv row is compared,
+    the rows of the hidden blocks must be exactly 0."""
+    B, H, L, S, D = 4, 8, 256, 1024, 128
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 31), ((B, H, S, D), 32), ((B, H, S, D), 33)))
+    do = _rand((B, H, L, D), dtype, dev, 34, std=1.0)
+    mask = torch.ones(B, 1, 1, S, dtype=torch.bool)
+    mask[0, ..., 640:] = False                    # three trailing blocks hidden
+    mask[1, ..., 128:384] = False                 # two blocks in the middle
+    mask[1, ..., 900:] = False                    # + a ragged tail
+    mask[2] = False
+    mask[2, ..., 517] = True                      # one visible key
+    mask = mask.to(dev)                           # batch 3: nothing hidden
+    gen = torch.Generator().manual_seed(5)
+    bias = (1.5 * torch.randn(H, L, S, generator=gen)).to(dtype).to(dev)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, attn_mask=mask, attn_bias=bias, is_causal=causal)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0, attn_mask=mask, attn_bias=bias, is_causal=causal)
+    _check(out, o, dtype, "out")
+    _check(q.grad, dq, dtype, "dq")
+    _check(k.grad, dk, dtype, "dk")
+    _check(v.grad, dv, dtype, "dv")
+    hidden = ~mask.view(B, S)
+    assert (k.grad.float().abs().amax(dim=(1, 3))[hidden] == 0).all() and (v.grad.float().abs().amax(dim=(1, 3))[hidden] == 0).all()
+
+
 # ---------------------------------------------------------------- key-padding masks (MODE_KEYPAD, MODE_BIAS_KEYPAD)
 @pytest.mark.parametrize("D", [32, 64, 128])
 @pytest.mark.parametrize("causal", [False, True])
