@@ -239,6 +239,9 @@ def _launch_fwd(q, k, v, mask, bias, n, scale, causal, dropout_p, rng):
     return o, lse
 
 
+_POISON_SCRATCH = False   # test hook: fill the backward's scratch (delta) with NaN before the launch
+
+
 class _FlashAttentionSoftmaxN(torch.autograd.Function):
     """autograd glue; same role as _FlashAttentionN (flash_attn_triton.py:241-336)."""
 
@@ -268,6 +271,8 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         dk = torch.empty((B, Hkv, S, D), dtype=q.dtype, device=dev)
         dv = torch.empty((B, Hkv, S, v.shape[3]), dtype=q.dtype, device=dev)
         delta = torch.empty((B, H, L), dtype=torch.float32, device=dev)
+        if _POISON_SCRATCH:   # tests: every kernel that reads delta must find it written (by fasn_bwd_delta or the dQ kernel's prologue)
+            delta.fill_(float("nan"))
         # plan: split kernels (default, deterministic) or the opt-in one-pass backward (fp32 atomics for dQ; never under
         # torch.use_deterministic_algorithms(True)) - see set_backward_plan()
         one_pass = _BACKWARD_PLAN == "one_pass" and not torch.are_deterministic_algorithms_enabled()

@@ -66,6 +66,70 @@ def test_causal_launches_that_pair_their_blocks(pkg, dev, L, S, dtype):
         _check(v.grad[sl], dv, dtype, f"dv[{b},{h}]")
 
 
+# ---------------------------------------------------------------- the backward's scratch
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", ["plain", "causal_rows_without_keys", "ragged", "keypad", "gqa", "bias", "dropout", "d32", "d128"])
+def test_backward_scratch_is_written_before_it_is_read(pkg, dev, monkeypatch, case, dtype):
+    """delta = rowsum(dO o O) is a scratch buffer of the caller's that fasn_bwd fills itself (fasn_bwd_delta_kernel; the reference's
+    _bwd_preprocess, core/flash_attn_triton.py:129-143). The scratch is filled with NaN first: every row the dQ / dK/dV kernels read
+    has to have been written (rows without a visible key and rows past a ragged end included - P = 0 there, and 0 x NaN would still
+    poison dK), the results have to be bit-identical to a run with a clean scratch and equal to the oracle's gradients."""
+    B, H, L, S, D = 2, 4, 200, 333, 64
+    kw, Hkv, drop = dict(softmax_n_param=1.0), 4, 0.0
+    if case == "causal_rows_without_keys":
+        L, S = 333, 200
+        kw["is_causal"] = True
+    elif case == "plain":
+        L, S = 512, 512
+    elif case == "keypad":
+        m = torch.ones(B, 1, 1, S, dtype=torch.bool, device=dev)
+        m[0, ..., 100:] = False
+        m[1, ..., 300:] = False
+        kw["attn_mask"] = m
+    elif case == "gqa":
+        Hkv = 2
+    elif case == "bias":
+        kw["attn_bias"] = (0.5 * torch.randn(1, H, L, S, device=dev)).to(dtype)
+    elif case == "dropout":
+        drop = 0.2
+    elif case == "d32":
+        D = 32
+    elif case == "d128":
+        D = 128
+    q = _rand((B, H, L, D), dtype, dev, 21).requires_grad_()
+    k, v = (_rand((B, Hkv, S, D), dtype, dev, s).requires_grad_() for s in (22, 23))
+    do = _rand((B, H, L, D), dtype, dev, 24, std=1.0)
+
+    def run():
+        for t in (q, k, v):
+            t.grad = None
+        torch.manual_seed(5)
+        out = pkg.flash_attention_n(q, k, v, dropout_p=drop, **kw)
+        out.backward(do)
+        return out.detach(), q.grad.clone(), k.grad.clone(), v.grad.clone()
+
+    clean = run()
+    monkeypatch.setattr(pkg.flash_attn, "_POISON_SCRATCH", True)
+    poisoned = run()
+    for a, b, nm in zip(clean, poisoned, ("out", "dq", "dk", "dv")):
+        assert torch.isfinite(b).all(), nm
+        assert torch.equal(a, b), nm
+    if case not in ("dropout",):
+        ke, ve = (t.repeat_interleave(H // Hkv, dim=1) for t in (k, v))
+        okw = dict(kw)
+        if "attn_mask" in okw:
+            okw["attn_mask"] = okw["attn_mask"].cpu()
+        if "attn_bias" in okw:
+            okw["attn_bias"] = okw["attn_bias"].float().cpu()
+        o, dq, dk, dv = _oracle_fwd_bwd(q, ke, ve, do, **okw)
+        g = H // Hkv
+        dk, dv = (t.reshape(B, Hkv, g, S, D).sum(2) for t in (dk, dv))
+        _check(poisoned[0], o, dtype, "out")
+        _check(poisoned[1], dq, dtype, "dq")
+        _check(poisoned[2], dk, dtype, "dk")
+        _check(poisoned[3], dv, dtype, "dv")
+
+
 # ---------------------------------------------------------------- the reference's own GPU test, same grid
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("is_causal", [False, True])
