@@ -131,6 +131,46 @@ FASN_DEV void kp_build_words(uint64_t* words, const uint8_t* mrow, int Sk, int n
     }
 }
 
+// Length-paired batch elements (forward and two-wave dQ kernels, bias broadcast over a key-padded batch). Every workgroup derives
+// the same plan from the key-padding mask [B,1,1,Sk]: walk length of batch element i = index of its last 16-key chunk with a visible
+// key + 1 (what the kernels' tile loops are bounded by), rank by (length descending, index ascending), pair slot r = (r-th longest,
+// r-th shortest); with an odd B the median element runs alone (b1 == b0). Returns false - plain schedule - when the mask does not
+// qualify (more than 64 batch elements or 64 KiB of mask, rows not movable in 16-byte pieces, a per-head mask) or when the
+// lengths differ by less than an eighth of the longest. `scratch`: B ints of LDS nobody uses yet; barriers inside, so the whole
+// workgroup calls it. Uniform result.
+constexpr int kPairMaxBatch = 64, kPairMaxBytes = 64 * 1024;
+FASN_DEV bool kpair_plan(const FwdParams& p, char* scratch, int tid, int slot, int& b0, int& b1) {
+    if (p.mask == nullptr || p.ms[1] != 0 || p.B < 2 || p.B > kPairMaxBatch || (int64_t)p.B * p.Sk > kPairMaxBytes || (p.Sk & 15) != 0 ||
+        (p.ms[0] & 15) != 0 || (reinterpret_cast<uintptr_t>(p.mask) & 15) != 0 || p.pair == 2)   // (pair 2 / 3: developer override)
+        return false;
+    int* const len = reinterpret_cast<int*>(scratch);
+    const int nthreads = (int)blockDim.x;
+    for (int i = tid; i < p.B; i += nthreads) len[i] = 0;
+    __syncthreads();
+    const int cpr = p.Sk >> 4;   // 16-byte chunks per mask row
+    for (int c = tid; c < p.B * cpr; c += nthreads) {
+        const int bb = c / cpr, k16 = c - bb * cpr;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(p.mask + (int64_t)bb * p.ms[0] + 16 * k16);
+        if ((w[0] | w[1] | w[2] | w[3]) != 0u) atomicMax(&len[bb], k16 + 1);
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int mine = lane < p.B ? len[lane] : -1;
+    __syncthreads();   // `len` has been read: the scratch may be reused by the caller
+    int rank = 0, lmax = 0, lmin = 0x7fffffff;
+    for (int k = 0; k < p.B; ++k) {
+        const int lk = __builtin_amdgcn_readlane(mine, k);
+        rank += (lk > mine || (lk == mine && k < lane)) ? 1 : 0;
+        lmax = max(lmax, lk);
+        lmin = min(lmin, lk);
+    }
+    if ((lmax - lmin) * 8 < lmax && p.pair != 3) return false;
+    const uint64_t m0 = __ballot(lane < p.B && rank == slot), m1 = __ballot(lane < p.B && rank == p.B - 1 - slot);
+    b0 = __builtin_ctzll(m0);
+    b1 = __builtin_ctzll(m1);
+    return true;
+}
+
 // DROP: attention-weight dropout compiled in (separate instantiations so the no-dropout kernels keep their registers).
 // RING: 1 = two staging register sets, K/V tiles are loaded TWO tiles ahead (the loop body is instantiated twice with the
 // sets swapped). One tile of lead is about 1.2 us at D=64, less than a first-touch HBM miss under load; in-order vmcnt
@@ -186,6 +226,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // are skipped, only the boundary tiles start their hidden scores at -inf. Key-padded batches cost what unpadded ones do.
     constexpr bool KP = mode_has_keypad(MODE);
     constexpr bool PAIRABLE = MODE == MODE_CAUSAL && !SPLIT && VH == 1 && !DROP;
+    constexpr bool KPAIR = KP && VBIAS && !SPLIT && VH == 1 && !DROP;   // length-paired batch elements (see below)
+    int bh2 = -1;   // KPAIR: the (b,h) of the second pass
     if (SPLIT) {
         int blk;
         block_to_work(wgid, p.B * p.H, p.nqblk * p.nsplit, bh, blk);
@@ -194,7 +236,23 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     } else if (GEN && p.batch_inner && (p.H & 7) == 0) {
         // per XCD: (head, q-block, batch) with the batch fastest -> the B workgroups that read the same bias tile run together
         const int xcd = wgid & 7, j = wgid >> 3;
-        const int bb = j % p.B, rest = j / p.B;
+        int bb = j % p.B, rest = j / p.B;
+        if constexpr (KPAIR) {
+            // Ragged key-padded batch under a batch-broadcast bias (C4): the B workgroups of a bias tile walk as many K/V tiles as
+            // their batch element has visible keys, and the in-order dispatcher makes every round as long as its longest workgroup
+            // (19 % of the C4 launch were idle CUs). Every workgroup reads the key-padding mask once (B x Sk bytes from L2), ranks
+            // the batch elements by their walk length and takes TWO of them, the r-th longest and then the r-th shortest: all
+            // workgroups of the launch cost about the same. The other half of the workgroup ids leaves at once (last ids = whole
+            // rounds). Batches of equal length keep the plain schedule (one bias fetch serves B workgroups instead of two).
+            int b0 = -1, b1 = -1;
+            if (kpair_plan(p, smem, tid, j % ((p.B + 1) / 2), b0, b1)) {
+                const int np = (p.B + 1) / 2;
+                if (j >= (p.H >> 3) * p.nqblk * np) return;
+                rest = j / np;
+                bb = b0;
+                if (b1 != b0) bh2 = b1 * p.H + (rest / p.nqblk) * 8 + xcd;
+            }
+        }
         qi = rest % p.nqblk;
         bh = bb * p.H + (rest / p.nqblk) * 8 + xcd;
     } else if (PAIRABLE && p.pair) {
@@ -207,9 +265,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // unequal causal blocks leave 7 % of the workgroup slots empty even when sorted by weight. Block r and block nqblk-1-r together
     // always walk nqblk + 1 tiles: every workgroup of a paired launch costs the same. Used when the launch is many rounds long
     // (equal workgroups quantise the last round).
-    const int npass = (PAIRABLE && p.pair && qi != p.nqblk - 1 - qi) ? 2 : 1;
+    const int npass = ((PAIRABLE && p.pair && qi != p.nqblk - 1 - qi) || (KPAIR && bh2 >= 0)) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
-    if (PAIRABLE && pass) __syncthreads();
+    if ((PAIRABLE || KPAIR) && pass) __syncthreads();
+    if (KPAIR && pass) bh = bh2;
     // causal: heaviest (last) query blocks first
     const int qblk = (MODE != MODE_PLAIN && p.causal) ? (pass == 0 ? p.nqblk - 1 - qi : qi) : qi;
     const int b = bh / p.H, h = bh % p.H;

@@ -66,6 +66,10 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
         p.pair = 1;
         blocks = (p.nqblk + 1) / 2;
     }
+#ifdef FASN_DEV_VARIANTS
+    // length-paired batch elements (kpair_plan): developer override through the same switch - 2 = never, 3 = whatever the lengths
+    if (mode_has_keypad(MODE) && mode_has_vbias(MODE) && g_pair_mode >= 0) p.pair = g_pair_mode ? 3 : 2;
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * p.B * p.H * VH)), dim3(NW * 64), smem, s, p);
     return launch_rc();
 }

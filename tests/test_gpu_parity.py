@@ -1161,6 +1161,33 @@ def test_padded_key_blocks_are_compacted_in_the_two_wave_dkdv_kernel(pkg, dev, d
     assert (k.grad.float().abs().amax(dim=(1, 3))[hidden] == 0).all() and (v.grad.float().abs().amax(dim=(1, 3))[hidden] == 0).all()
 
 
+# ---------------------------------------------------------------- length-paired batch elements (csrc/fasn_fwd_kernel.h kpair_plan)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("lengths", [(1024, 896, 768, 512), (300, 1024, 1024, 77, 640), (1024, 1024, 1024, 960), (1, 1024), (0, 512, 1024)])
+def test_ragged_key_padded_batch_under_a_broadcast_bias_is_length_paired(pkg, dev, lengths, D, dtype):
+    """A bias broadcast over the batch next to a [B,1,1,S] key-padding mask with ragged lengths (BASELINE config 4's structure): the
+    forward and dQ workgroups take two batch elements each, the r-th longest and the r-th shortest (in-order dispatcher: equal
+    workgroups), half of the workgroup ids leave at once. Even and odd batch sizes (the median element runs alone), ties, lengths
+    that are nearly equal (plain schedule kept), a batch element with one / with no visible key; forward + dq/dk/dv against the oracle."""
+    B, H, L, S = len(lengths), 8, 256, 1024
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 41), ((B, H, S, D), 42), ((B, H, S, D), 43)))
+    do = _rand((B, H, L, D), dtype, dev, 44, std=1.0)
+    mask = torch.zeros(B, 1, 1, S, dtype=torch.bool)
+    for b, n in enumerate(lengths):
+        mask[b, ..., :n] = True
+    mask = mask.to(dev)
+    gen = torch.Generator().manual_seed(6)
+    bias = (1.5 * torch.randn(H, L, S, generator=gen)).to(dtype).to(dev)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, attn_mask=mask, attn_bias=bias)
+    out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0, attn_mask=mask, attn_bias=bias)
+    _check(out, o, dtype, "out")
+    _check(q.grad, dq, dtype, "dq")
+    _check(k.grad, dk, dtype, "dk")
+    _check(v.grad, dv, dtype, "dv")
+
+
 # ---------------------------------------------------------------- key-padding masks (MODE_KEYPAD, MODE_BIAS_KEYPAD)
 @pytest.mark.parametrize("D", [32, 64, 128])
 @pytest.mark.parametrize("causal", [False, True])

@@ -78,7 +78,7 @@ struct Rng {
 struct Problem {
     int B, H, Sq, Sk, D, dtype, causal;
     float scale, n;
-    int mask_kind;  // 0 none, 1 key-padding [B,1,1,Sk], 2 dense random [B,H,Sq,Sk]
+    int mask_kind;  // 0 none, 1 key-padding [B,1,1,Sk], 2 dense random [B,H,Sq,Sk], 3 key-padding layout with every key visible, 4 key-padding with bench.py's lengths
     int bias_kind;  // 0 none, 1 alibi [H,Sq,Sk] same dtype, 2 random f32 [B,H,Sq,Sk]
     float std;
 };
@@ -102,10 +102,11 @@ static void make_inputs(const Problem& P, Host& h, uint64_t seed) {
     for (auto& x : h.k) x = enc(r.normal(P.std), P.dtype);
     for (auto& x : h.v) x = enc(r.normal(P.std), P.dtype);
     for (auto& x : h.dout) x = enc(r.normal(1.0f), P.dtype);
-    if (P.mask_kind == 1) {
+    if (P.mask_kind == 1 || P.mask_kind == 3 || P.mask_kind == 4) {
         h.mask.resize((size_t)P.B * P.Sk);
+        static const int eighths[4] = {8, 7, 6, 4};   // kind 4: bench.py's keypad_mask lengths (S, 7S/8, 3S/4, S/2, repeating)
         for (int b = 0; b < P.B; ++b) {
-            int valid = P.Sk - (b * P.Sk) / (2 * P.B);
+            int valid = P.mask_kind == 3 ? P.Sk : P.mask_kind == 4 ? P.Sk * eighths[b % 4] / 8 : P.Sk - (b * P.Sk) / (2 * P.B);
             for (int j = 0; j < P.Sk; ++j) h.mask[(size_t)b * P.Sk + j] = j < valid;
         }
         h.ms[0] = P.Sk; h.ms[1] = 0; h.ms[2] = 0; h.ms[3] = 1;

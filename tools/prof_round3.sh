@@ -42,4 +42,10 @@ for l in open("$O/bench_all.jsonl"):
     d=json.loads(l); r=d["roofline"]
     print("%-64s %8.3f ms/step kernels %8.3f ms  alg %7.1f TF (%.3f) exec %.3f traffic %s" % (d["config"]["workload"][:64], d["ms_per_step"], r["kernel_ms"], r["achieved"], r["frac"], r["frac_executed"], r["traffic"]))
 PY
+# clock / socket power under load (rocm-smi): the chip runs these kernels at its power cap
+{
+for a in "8 16 4096 4096 64 1 0 0 20000 0 1.0 0 0" "8 16 4096 4096 64 1 0 0 5000 1 1.0 0 0" "8 16 4096 4096 64 1 1 0 20000 0 1.0 0 0" "4 32 8192 8192 128 1 0 0 2000 0 0.5 0 0" "4 32 8192 8192 128 1 0 0 2000 0 0.5 4 1" "4 32 8192 8192 128 1 0 0 500 1 0.5 4 1"; do
+  echo "== harness bench $a"; bash $R/tools/clock_probe.sh $a
+done
+} > $O/clocks.log 2>&1
 du -sh $O
