@@ -90,6 +90,43 @@ def pmc_traffic(workload, which):
         return None
 
 
+def gpu_sensors(index):
+    """Shader clock (MHz) and socket power (W) of GPU `index` from the amdgpu hwmon files (what rocm-smi prints), read while the
+    roofline loop's launches are still queued; None where the box does not expose them. The kernels here hold the socket at its
+    power limit, so the clock under load - not the nominal 2.4 GHz behind PEAK_TFLOPS - is what the matrix pipes run at."""
+    import glob
+    try:
+        import torch
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if glob.glob(c + "/hwmon/hwmon*/freq1_input")]
+        if want:
+            hit = [c for c in cards if want in os.path.realpath(c)]
+            cards = hit or cards
+        elif index < len(cards):
+            cards = [cards[index]]
+        if not cards:
+            return None, None
+        h = glob.glob(cards[0] + "/hwmon/hwmon*")[0]
+        rd = lambda f: int(open(os.path.join(h, f)).read().strip())
+        mhz = rd("freq1_input") / 1e6
+        watts = None
+        for f in ("power1_average", "power1_input"):
+            try:
+                watts = rd(f) / 1e6
+                break
+            except Exception:
+                continue
+        return mhz, watts
+    except Exception:
+        return None, None
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -255,6 +292,8 @@ def main():
 
         steps_of = {"fwd": step_fwd, "bwd": step_bwd, "fwdbwd": step_fwdbwd}
 
+        sensors = []
+
         def kernel_time(fn, iters):
             """average duration of back-to-back launches: events on the launch stream (torch's current stream IS the stream
             the ctypes call launches on), >= 200 launches so the clocks settle"""
@@ -265,6 +304,8 @@ def main():
             for _ in range(iters):
                 fn()
             e1.record()
+            if sensors is not None and not e1.query():   # the launches are still running: clock / power under THIS load
+                sensors.append(gpu_sensors(dev.index or 0))
             e1.synchronize()
             return e0.elapsed_time(e1) / iters
 
@@ -327,6 +368,11 @@ def main():
             "gemm_equivalents": {"algorithmic": (GEMMS256 if D > 128 else GEMMS)[args.which][0], "executed": (GEMMS256 if D > 128 else GEMMS)[args.which][1]},
             "frac_executed": exe / (kernel_ms * 1e-3) / 1e12 / peak,
             **({"visible_key_tile_fraction": vis} if vis < 1.0 else {})}
+        sm = [x for x in sensors if x[0]]
+        if sm:   # nominal peak scaled to the clock the part held during the roofline loop (informative; `frac` stays against the nominal peak)
+            mhz, watts = sm[0]
+            line["roofline"]["under_load"] = {"sclk_mhz": mhz, "socket_power_w": watts, "nominal_mhz": 2400.0,
+                                              "frac_of_clock_adjusted_peak": achieved / (peak * mhz / 2400.0)}
         if args.backward_plan == "one_pass" and args.which != "fwd":
             line["roofline"]["kernels"] = "fasn_bwd_delta + fasn_bwd_fused + fasn_bwd_dq_convert (one-pass plan)"
         line.update(extra)
