@@ -105,9 +105,8 @@ def gpu_sensors(index):
             pass
         cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
         cards = [c for c in cards if glob.glob(c + "/hwmon/hwmon*/freq1_input")]
-        if want:
-            hit = [c for c in cards if want in os.path.realpath(c)]
-            cards = hit or cards
+        if want:   # this process's GPU only (a host may expose other tenants' cards too)
+            cards = [c for c in cards if want in os.path.realpath(c)]
         elif index < len(cards):
             cards = [cards[index]]
         if not cards:
@@ -304,8 +303,18 @@ def main():
             for _ in range(iters):
                 fn()
             e1.record()
-            if sensors is not None and not e1.query():   # the launches are still running: clock / power under THIS load
-                sensors.append(gpu_sensors(dev.index or 0))
+            # the launches are still running: sample clock / power under THIS load until they are done (a read is ~0.1 ms of host
+            # time; the last clock before completion and the highest power reading are kept - the power sensor lags the load)
+            last, pmax = None, None
+            while not e1.query():
+                mhz, watts = gpu_sensors(dev.index or 0)
+                if mhz is None:
+                    break
+                last = mhz
+                pmax = watts if pmax is None or (watts is not None and watts > pmax) else pmax
+                time.sleep(0.004)
+            if last is not None:
+                sensors.append((last, pmax))
             e1.synchronize()
             return e0.elapsed_time(e1) / iters
 
