@@ -205,6 +205,8 @@ def main():
                     help="fasn_bwd plan: the deterministic dQ + dK/dV split (default) or the opt-in one-pass backward (D = 64, plain / causal)")
     ap.add_argument("--pass", dest="which", default="fwd", choices=["fwd", "bwd", "fwdbwd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-launches", type=int, default=0,
+                    help="back-to-back launches of the roofline loop (default: 200 forward / 60 backward; counter passes of the profile scripts use fewer)")
     ap.add_argument("--no-extra-passes", action="store_true", help="default forward run: skip the backward / fwdbwd objects")
     ap.add_argument("--stub-step-ms", type=float, default=None,
                     help="testing only: replace the GPU step by a sleep of this many ms (exercises launch + aggregation on CPU)")
@@ -328,7 +330,7 @@ def main():
         raw = {"fwd": (lambda: lib.fasn_fwd_ws(fargs, fws.data_ptr(), fws_bytes, stream)) if fws_bytes else (lambda: lib.fasn_fwd(fargs, stream)),
                "bwd": lambda: lib.fasn_bwd(bargs, stream)}
         if args.which in raw:
-            kernel_ms = kernel_time(raw[args.which], max(200 if args.which == "fwd" else 60, args.steps))
+            kernel_ms = kernel_time(raw[args.which], args.roofline_launches or max(200 if args.which == "fwd" else 60, args.steps))
         else:
             kernel_ms = kernel_time(raw["fwd"], 100) + kernel_time(raw["bwd"], 60)
 

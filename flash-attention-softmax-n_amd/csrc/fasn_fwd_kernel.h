@@ -136,7 +136,7 @@ FASN_DEV void kp_build_words(uint64_t* words, const uint8_t* mrow, int Sk, int n
 // key + 1 (what the kernels' tile loops are bounded by), rank by (length descending, index ascending), pair slot r = (r-th longest,
 // r-th shortest); with an odd B the median element runs alone (b1 == b0). Returns false - plain schedule - when the mask does not
 // qualify (more than 64 batch elements or 64 KiB of mask, rows not movable in 16-byte pieces, a per-head mask) or when the
-// lengths differ by less than an eighth of the longest. `scratch`: B ints of LDS nobody uses yet; barriers inside, so the whole
+// batch is not ragged enough to pay for it (mean length >= 0.85 of the longest). `scratch`: B ints of LDS nobody uses yet; barriers inside, so the whole
 // workgroup calls it. Uniform result.
 constexpr int kPairMaxBatch = 64, kPairMaxBytes = 64 * 1024;
 FASN_DEV bool kpair_plan(const FwdParams& p, char* scratch, int tid, int slot, int& b0, int& b1) {
@@ -157,14 +157,16 @@ FASN_DEV bool kpair_plan(const FwdParams& p, char* scratch, int tid, int slot, i
     const int lane = tid & 63;
     const int mine = lane < p.B ? len[lane] : -1;
     __syncthreads();   // `len` has been read: the scratch may be reused by the caller
-    int rank = 0, lmax = 0, lmin = 0x7fffffff;
+    int rank = 0, lmax = 0, lsum = 0;
     for (int k = 0; k < p.B; ++k) {
         const int lk = __builtin_amdgcn_readlane(mine, k);
         rank += (lk > mine || (lk == mine && k < lane)) ? 1 : 0;
         lmax = max(lmax, lk);
-        lmin = min(lmin, lk);
+        lsum += lk;
     }
-    if ((lmax - lmin) * 8 < lmax && p.pair != 3) return false;
+    // worth it? the plain schedule costs max(len) per round, the paired one about mean(len) x 1.18 (measured: its tile steps are
+    // slower, the bias is fetched twice): pair when the mean walk length is below 0.85 of the longest
+    if ((int64_t)lsum * 20 >= (int64_t)lmax * p.B * 17 && p.pair != 3) return false;
     const uint64_t m0 = __ballot(lane < p.B && rank == slot), m1 = __ballot(lane < p.B && rank == p.B - 1 - slot);
     b0 = __builtin_ctzll(m0);
     b1 = __builtin_ctzll(m1);
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             // (19 % of the C4 launch were idle CUs). Every workgroup reads the key-padding mask once (B x Sk bytes from L2), ranks
             // the batch elements by their walk length and takes TWO of them, the r-th longest and then the r-th shortest: all
             // workgroups of the launch cost about the same. The other half of the workgroup ids leaves at once (last ids = whole
-            // rounds). Batches of equal length keep the plain schedule (one bias fetch serves B workgroups instead of two).
+            // rounds). Batches that are not ragged enough keep the plain schedule (one bias fetch serves B workgroups instead of two).
             int b0 = -1, b1 = -1;
             if (kpair_plan(p, smem, tid, j % ((p.B + 1) / 2), b0, b1)) {
                 const int np = (p.B + 1) / 2;

@@ -94,3 +94,13 @@ def test_bench_flop_model():
     assert abs(bench.fwd_flops(8, 16, 4096, 64, True) / 274.9e9 - 1) < 1e-3
     alg, exe = bench.pass_flops("bwd", 8, 16, 4096, 64, False)   # 5 GEMM-equivalents in the textbook backward, 7 executed
     assert alg == 2.5 * 549755813888.0 and exe == 3.5 * 549755813888.0
+
+
+def test_gpu_sensors_without_a_gpu_returns_none():
+    """bench.py's clock / power probe (roofline.under_load) must never raise: on a box without amdgpu hwmon files (this container)
+    it reports (None, None) and the bench line simply omits the object."""
+    sys.path.insert(0, ROOT)
+    import bench
+    mhz, watts = bench.gpu_sensors(0)
+    assert mhz is None or mhz > 0
+    assert watts is None or watts >= 0

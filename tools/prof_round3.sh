@@ -12,7 +12,7 @@ run() {   # run NAME "bench args" counter-set...   (NAME = workload_pass)
   n=$1; B="python $R/bench.py $2 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-passes"; shift 2; D=$O/$n; mkdir -p $D
   timeout 300 rocprofv3 --kernel-trace --stats -d $D/kt -o kt -- $B > $D/kt.log 2>&1
   for set in "$@"; do
-    c=$(echo $set | cut -d" " -f1); timeout 300 rocprofv3 --pmc $set -d $D/pmc_$c -o pmc -- $B > $D/pmc_$c.log 2>&1
+    c=$(echo $set | cut -d" " -f1); timeout 300 rocprofv3 --pmc $set -d $D/pmc_$c -o pmc -- $B --roofline-launches 40 > $D/pmc_$c.log 2>&1   # (counters are per-dispatch averages; 215 serialised C5 launches ran into the limit on slow boxes)
   done
   python3 $R/tools/pmc_summary.py $D fasn_ > $D/summary.txt 2>&1
   python3 $R/tools/pmc_to_json.py $O $R/flash-attention-softmax-n_amd/libfasn.so $n > /dev/null 2>&1
