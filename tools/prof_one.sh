@@ -7,7 +7,7 @@ SQ1="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE
 n=${W}_$P; B="python $R/bench.py --workload $W --pass $P --steps 3 --warmup 1 --no-cpu-baseline --no-extra-passes"; D=$O/$n; mkdir -p $D
 timeout 600 rocprofv3 --kernel-trace --stats -d $D/kt -o kt -- $B > $D/kt.log 2>&1
 for set in FETCH_SIZE WRITE_SIZE "$SQ1"; do
-  c=$(echo $set | cut -d" " -f1); timeout 600 rocprofv3 --pmc $set -d $D/pmc_$c -o pmc -- $B > $D/pmc_$c.log 2>&1
+  c=$(echo $set | cut -d" " -f1); timeout 600 rocprofv3 --pmc $set -d $D/pmc_$c -o pmc -- $B --roofline-launches 40 > $D/pmc_$c.log 2>&1
 done
 python3 $R/tools/pmc_summary.py $D fasn_ > $D/summary.txt 2>&1
 python3 $R/tools/pmc_to_json.py $O $R/flash-attention-softmax-n_amd/libfasn.so $n > /dev/null 2>&1
