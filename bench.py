@@ -305,18 +305,6 @@ def main():
             for _ in range(iters):
                 fn()
             e1.record()
-            # the launches are still running: sample clock / power under THIS load until they are done (a read is ~0.1 ms of host
-            # time; the last clock before completion and the highest power reading are kept - the power sensor lags the load)
-            last, pmax = None, None
-            while not e1.query():
-                mhz, watts = gpu_sensors(dev.index or 0)
-                if mhz is None:
-                    break
-                last = mhz
-                pmax = watts if pmax is None or (watts is not None and watts > pmax) else pmax
-                time.sleep(0.004)
-            if last is not None:
-                sensors.append((last, pmax))
             e1.synchronize()
             return e0.elapsed_time(e1) / iters
 
@@ -336,6 +324,28 @@ def main():
 
         dt = timed(ctl, steps_of[args.which], sync, args.steps, args.warmup)
 
+        def sample_under_load(fn, ms):
+            """Clock / power under THIS load, AFTER everything that is timed: about 0.4 s of back-to-back launches, the amdgpu
+            hwmon sensors polled while they run (the last clock before completion and the highest power reading are kept - the
+            power sensor lags the load). Its own loop on purpose: polled inside the roofline loop, the sensor reads (SMU
+            queries) made the timed steps that followed 11 % slower."""
+            n = int(min(2000, max(50, 400.0 / max(ms, 1e-3))))
+            e1 = torch.cuda.Event()
+            for _ in range(n):
+                fn()
+            e1.record()
+            last, pmax = None, None
+            while not e1.query():
+                mhz, watts = gpu_sensors(dev.index or 0)
+                if mhz is None:
+                    break
+                last = mhz
+                pmax = watts if pmax is None or (watts is not None and watts > pmax) else pmax
+                time.sleep(0.01)
+            e1.synchronize()
+            if last is not None:
+                sensors.append((last, pmax))
+
         if args.which == "fwd" and args.workload == "m0" and world == 1 and not args.no_extra_passes:
             # driver-visible backward numbers next to the headline (same K and W, measured after the headline's timed region)
             for w in ("bwd", "fwdbwd"):
@@ -347,6 +357,9 @@ def main():
                     "algorithmic_tflops": alg / (dtw / args.steps) / 1e12, "executed_tflops": exe / (dtw / args.steps) / 1e12,
                     "frac_of_peak_algorithmic": alg / (dtw / args.steps) / 1e12 / PEAK_TFLOPS,
                     **({"kernels_ms": kms, "kernels_frac_of_peak_executed": exe / (kms * 1e-3) / 1e12 / PEAK_TFLOPS} if kms else {})}
+
+        if rank == 0:
+            sample_under_load(raw[args.which] if args.which in raw else raw["bwd"], kernel_ms)
 
     if rank != 0:
         ctl.close()
