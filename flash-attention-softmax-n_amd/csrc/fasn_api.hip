@@ -356,6 +356,7 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
         p.dobytes = (unsigned)db;
     }
     p.dqacc = nullptr;
+    p.skip = 0;
     if (bwd_fused_applies(a, fp, l) && a->workspace != nullptr && a->workspace_bytes >= bwd_fused_bytes(a)) {
         if (reinterpret_cast<uintptr_t>(a->workspace) % 16) return FASN_EALIGN;
         p.dqacc = static_cast<float*>(a->workspace);

@@ -12,6 +12,21 @@ int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
 #endif
     if (p.dqacc != nullptr)   // fasn_api.hip sets the accumulator only where the one-pass backward applies (plain / causal, no dropout, no GQA)
         return launch_bwd_fused_d64(p, l, s);
-    return l.dtype == 1 ? launch_bwd_mode<bf16_tag, 64, 1, 1, 2, 2>(p, l.mode, s) : launch_bwd_mode<f16_tag, 64, 1, 1, 2, 2>(p, l.mode, s);
+    // plain / causal without dropout or grouped K/V: the software-pipelined kernels of fasn_bwd_pipe.h
+    // (developer library: bwd_variant bit 6 / bit 7 = the round-3 dK/dV / dQ kernel instead, for same-box A/B)
+    BwdParams q = p;
+    q.skip = 0;
+    const bool pipe_ok = (l.mode == MODE_PLAIN || l.mode == MODE_CAUSAL) && p.f.drop_thr == 0 && p.f.kvg == 1;
+    if (pipe_ok && !(FASN_BWD_VARIANT & 64)) q.skip |= 1;
+    if (pipe_ok && !(FASN_BWD_VARIANT & 128)) q.skip |= 2;
+    int rc = l.dtype == 1 ? launch_bwd_mode<bf16_tag, 64, 1, 1, 2, 2>(q, l.mode, s) : launch_bwd_mode<f16_tag, 64, 1, 1, 2, 2>(q, l.mode, s);
+    if (rc) return rc;
+    if (q.skip & 2) rc = launch_bwd_dq_pipe_d64(p, l, s);
+    if (rc) return rc;
+#ifdef FASN_DEV_VARIANTS
+    if ((q.skip & 1) && (FASN_BWD_VARIANT & 1024)) return launch_bwd_dkdv_pipe2_d64(p, l, s);   // one wave per SIMD, 64 keys per wave
+#endif
+    if (q.skip & 1) rc = launch_bwd_dkdv_pipe_d64(p, l, s);
+    return rc;
 }
 }  // namespace fasn

@@ -37,6 +37,7 @@ struct BwdParams {
     int64_t dbs[3];
     int dbias_vec;     // rows 16-byte aligned: 8 keys per store on the vector path
     float* dqacc;      // fused backward (fasn_bwd_fused.h): fp32 dQ accumulator [B,H,Sq,D] in the caller's workspace; nullptr = split kernels
+    int skip;          // host side only (launch_bwd_one): bit 0 = dK/dV, bit 1 = dQ are launched by the caller (fasn_bwd_pipe.h kernels)
 };
 
 // ---------------------------------------------------------------------------------------------

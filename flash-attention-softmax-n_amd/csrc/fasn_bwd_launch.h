@@ -14,6 +14,9 @@ int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d128(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d256(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_fused_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);   // one-pass backward (fasn_bwd_fused.h), p.dqacc set
+int launch_bwd_dkdv_pipe_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
+int launch_bwd_dkdv_pipe2_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);  // the same with one wave per SIMD and 64 keys per wave (developer A/B)
+int launch_bwd_dq_pipe_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);     // software-pipelined dQ   // software-pipelined dK/dV (fasn_bwd_pipe.h): plain / causal
 int launch_bwd_dbias(const BwdParams& p, const FwdLaunch& l, int Bb, int Hb, int out_f32, hipStream_t s);   // batch- / head-reduced bias gradient (fasn_bwd_dbias.h)
 
 // developer switch (FASN_DEV_VARIANTS builds only): bit 0 = take the one-wave dK/dV kernel where the two-wave kernel is the default,
@@ -34,10 +37,10 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         const int64_t rows = (int64_t)nbh * p.f.Sq;
         hipLaunchKernelGGL((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
     }
-    bool dq_done = false;
+    bool dq_done = (p.skip & 2) != 0;
     if constexpr (WS != 0 && DROP == 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
         const int ntiles = (p.f.Sk + KT - 1) / KT;
-        if (!(FASN_BWD_VARIANT & 2) && (!mode_has_keypad(MODE) || ntiles <= kDqWsMaxTiles)) {   // dQ: two cooperating waves per row block
+        if (!dq_done && !(FASN_BWD_VARIANT & 2) && (!mode_has_keypad(MODE) || ntiles <= kDqWsMaxTiles)) {   // dQ: two cooperating waves per row block
             constexpr int smem = 5 * KT * D * 2 + 2 * 16384 + (mode_has_vbias(MODE) ? 32768 : 0) + (mode_has_keypad(MODE) ? kDqWsMaxTiles * 8 : 0);
             p.nblk = (p.f.Sq + 127) / 128;
             constexpr auto kern = &fasn_bwd_dq_ws_kernel<Tag, D, MODE>;
@@ -57,6 +60,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
         p.f.pair = 0;
     }
+    if (p.skip & 1) return launch_rc();
     if constexpr (WS != 0 && DROP == 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
         if (!(FASN_BWD_VARIANT & 1)) {   // dK, dV: two cooperating waves per key block
             constexpr int smem = 6 * QT * D * 2 + 2 * 16384 + 6 * QT * 4 + (mode_has_vbias(MODE) ? 4 * 3 * 2048 : 0);

@@ -1,0 +1,58 @@
+// Software-pipelined backward kernels (fasn_bwd_pipe.h), D = 64 plain / causal: launch plumbing.
+#include "fasn_bwd_launch.h"
+#include "fasn_bwd_pipe.h"
+namespace fasn {
+
+template <typename Tag, int MODE>
+static int launch_dkdv_pipe(BwdParams p, hipStream_t s) {
+    constexpr int BN = 128;
+    constexpr int smem = pipe_dkdv_smem_bytes();
+    const int nbh = p.f.B * p.f.H;
+    p.nblk = (p.f.Sk + BN - 1) / BN;
+    constexpr auto kern = &fasn_bwd_dkdv_pipe_kernel<Tag, MODE>;
+    ensure_smem<kern>(smem);
+    p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * 2)) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
+    return launch_rc();
+}
+
+template <typename Tag, int MODE>
+static int launch_dq_pipe(BwdParams p, hipStream_t s) {
+    constexpr int BM = 128;
+    constexpr int smem = pipe_dq_smem_bytes();
+    const int nbh = p.f.B * p.f.H;
+    p.nblk = (p.f.Sq + BM - 1) / BM;
+    constexpr auto kern = &fasn_bwd_dq_pipe_kernel<Tag, MODE>;
+    ensure_smem<kern>(smem);
+    p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * 2)) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
+    return launch_rc();
+}
+
+int launch_bwd_dq_pipe_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (l.mode == MODE_CAUSAL) return l.dtype == 1 ? launch_dq_pipe<bf16_tag, MODE_CAUSAL>(p, s) : launch_dq_pipe<f16_tag, MODE_CAUSAL>(p, s);
+    return l.dtype == 1 ? launch_dq_pipe<bf16_tag, MODE_PLAIN>(p, s) : launch_dq_pipe<f16_tag, MODE_PLAIN>(p, s);
+}
+
+template <typename Tag, int MODE, int KB>
+static int launch_dkdv_pipe2(BwdParams p, hipStream_t s) {
+    constexpr int BN = 4 * KB * 32;
+    constexpr int smem = pipe_dkdv_smem_bytes();
+    const int nbh = p.f.B * p.f.H;
+    p.nblk = (p.f.Sk + BN - 1) / BN;
+    constexpr auto kern = &fasn_bwd_dkdv_pipe2_kernel<Tag, MODE, KB>;
+    ensure_smem<kern>(smem);
+    p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L)) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
+    return launch_rc();
+}
+int launch_bwd_dkdv_pipe2_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (l.mode == MODE_CAUSAL) return l.dtype == 1 ? launch_dkdv_pipe2<bf16_tag, MODE_CAUSAL, 2>(p, s) : launch_dkdv_pipe2<f16_tag, MODE_CAUSAL, 2>(p, s);
+    return l.dtype == 1 ? launch_dkdv_pipe2<bf16_tag, MODE_PLAIN, 2>(p, s) : launch_dkdv_pipe2<f16_tag, MODE_PLAIN, 2>(p, s);
+}
+
+int launch_bwd_dkdv_pipe_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (l.mode == MODE_CAUSAL) return l.dtype == 1 ? launch_dkdv_pipe<bf16_tag, MODE_CAUSAL>(p, s) : launch_dkdv_pipe<f16_tag, MODE_CAUSAL>(p, s);
+    return l.dtype == 1 ? launch_dkdv_pipe<bf16_tag, MODE_PLAIN>(p, s) : launch_dkdv_pipe<f16_tag, MODE_PLAIN>(p, s);
+}
+}  // namespace fasn

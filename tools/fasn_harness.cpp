@@ -465,6 +465,10 @@ static int do_test(int variant, bool quick) {
         {"d64 bf16 1100x1300 causal n1", mk(1, 2, 1100, 1300, 64, BF, 1, 1.f), true},
         {"d64 f16 1300x1100 causal n0", mk(1, 2, 1300, 1100, 64, HF, 1, 0.f), true},
         {"d64 f16 33x1000 n1", mk(2, 2, 33, 1000, 64, HF, 0, 1.f), true},
+        {"d64 bf16 (4,16,2048) causal n1 (paired blocks)", mk(4, 16, 2048, 2048, 64, BF, 1, 1.f), true},
+        {"d64 f16 (2,4,1000x1536) causal n0", mk(2, 4, 1000, 1536, 64, HF, 1, 0.f), true},
+        {"d64 bf16 1x64 n1", mk(1, 1, 1, 64, 64, BF, 0, 1.f), true},
+        {"d64 bf16 65x1 causal n1", mk(1, 2, 65, 1, 64, BF, 1, 1.f), true},
     };
     if (!quick) {
         cases.push_back({"d64 bf16 (8,16,1024) n1", mk(8, 16, 1024, 1024, 64, BF, 0, 1.f), true});
@@ -627,6 +631,7 @@ int main(int argc, char** argv) {
         return 2;
     }
     if (const char* pm = getenv("FASN_PAIR")) fasn_dev_set_pair_mode(atoi(pm));
+    if (const char* bv = getenv("FASN_BWDV")) fasn_dev_set_bwd_variant(atoi(bv));   // backward kernel variant for `test` (bench takes it as an argument)
     std::string cmd = argv[1];
     if (cmd == "probe") return do_probe();
     if (cmd == "test") {
