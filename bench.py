@@ -2,7 +2,7 @@
 """bench.py — headline benchmark of the hot path (BASELINE.json): attn-ops/s of flash_attention_n at
 (B=8, H=16, S=4096, D=64) bf16, n=1, non-causal, on N replicated GPUs (no sharding, no RCCL on the data path).
 
-  python bench.py --gpus N --steps K --warmup W [--workload m0|c1|c2|c3|c4|c5|d256] [--pass fwd|bwd|fwdbwd] [--backward-plan split|one_pass]
+  python bench.py --gpus N --steps K --warmup W [--workload m0|c1|c2|c3|c4|c5|d256] [--pass fwd|bwd|fwdbwd]
 
 N > 1: bench.py launches its own N replica processes (one per GPU, gloo control plane over 127.0.0.1) when it is started
 without WORLD_SIZE; started under `python -m torch.distributed.run --nproc-per-node N ...` it joins that world instead.
@@ -69,6 +69,12 @@ def visible_tile_fraction(B, S, tile=64):
     return sum(-(-int(S * fr[b % 4]) // tile) for b in range(B)) * tile / float(B * S)
 
 
+def visible_key_fraction(B, S):
+    """share of the (batch, key) pairs that are visible under synth.keypad_mask's lengths: the scores a padded batch actually needs"""
+    fr = [1.0, 0.875, 0.75, 0.5]
+    return sum(int(S * fr[b % 4]) for b in range(B)) / float(B * S)
+
+
 def lib_sha256():
     path = os.path.join(ROOT, "flash-attention-softmax-n_amd", "libfasn.so")
     h = hashlib.sha256()
@@ -85,6 +91,9 @@ def pmc_traffic(workload, which):
         d = json.load(open(prof))
         if d.get("libfasn_sha256") != lib_sha256():
             return None
+        if which == "fwdbwd":   # one forward launch + one fasn_bwd: the sum of the two passes' counters
+            parts = [d.get(f"{workload}:{w}", {}).get("hbm_bytes_per_launch") for w in ("fwd", "bwd")]
+            return None if None in parts else parts[0] + parts[1]
         return d.get(f"{workload}:{which}", {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
@@ -174,24 +183,47 @@ class Control:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather(self, obj):
+        """every rank's `obj` on rank 0 (a list in rank order; None elsewhere)"""
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(obj, out, dst=0)
+        return out
+
     def close(self):
         if self.world > 1:
             self.dist.destroy_process_group()
 
 
-def timed(ctl, step, sync, steps, warmup):
-    """W untimed warm-up steps, then EXACTLY K steps between barrier + device sync on both sides; MAX over ranks."""
+MIN_TIMED_S = 0.05   # a timed region shorter than this is mostly launch / sync jitter (20 steps of the M0 forward are 10 ms)
+
+
+def timed(ctl, step, sync, steps, warmup, info=None):
+    """W untimed warm-up steps, then the timed region between barrier + device sync on both sides; MAX over ranks. The region is K
+    steps, repeated in whole blocks of K until it lasts at least MIN_TIMED_S (the block count comes from one untimed pilot block and
+    is agreed across ranks); the returned time is that of ONE block of K steps, `info` gets the block count and this rank's own time."""
     for _ in range(warmup):
         step()
     sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):   # pilot block (untimed in the result): how long do K steps take here?
+        step()
+    sync()
+    pilot = max(time.perf_counter() - t0, 1e-6)
+    blocks = int(ctl.max(float(max(1, -(-MIN_TIMED_S // pilot)))))
+    blocks = min(blocks, 10000)
     ctl.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(blocks * steps):
         step()
     sync()
-    dt = time.perf_counter() - t0
+    dt = (time.perf_counter() - t0) / blocks
     ctl.barrier()
+    if info is not None:
+        info["timed_steps"] = blocks * steps
+        info["local_ms_per_step"] = dt / steps * 1e3
     return ctl.max(dt)
 
 
@@ -201,8 +233,6 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="m0", choices=sorted(WORKLOADS))
-    ap.add_argument("--backward-plan", default="split", choices=["split", "one_pass"],
-                    help="fasn_bwd plan: the deterministic dQ + dK/dV split (default) or the opt-in one-pass backward (D = 64, plain / causal)")
     ap.add_argument("--pass", dest="which", default="fwd", choices=["fwd", "bwd", "fwdbwd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-launches", type=int, default=0,
@@ -224,6 +254,7 @@ def main():
 
     B, H, S, D, dname, n, causal = WORKLOADS[args.workload]
     vis = visible_tile_fraction(B, S) if args.workload == "c4" else 1.0
+    visk = visible_key_fraction(B, S) if args.workload == "c4" else 1.0
     peak = PEAK_TFLOPS_F32 if dname == "f32" else PEAK_TFLOPS
     stub = args.stub_step_ms is not None
     ctl = Control(rank, world)
@@ -232,7 +263,8 @@ def main():
     if stub:
         def step():
             time.sleep(args.stub_step_ms * 1e-3 * (1 + rank))   # rank-dependent: the MAX over ranks is rank N-1's time
-        dt = timed(ctl, step, lambda: None, args.steps, args.warmup)
+        tinfo = {}
+        dt = timed(ctl, step, lambda: None, args.steps, args.warmup, tinfo)
     else:
         import ctypes  # noqa: F401
         import torch
@@ -246,7 +278,6 @@ def main():
         import flash_attention_softmax_n_amd as pkg
         from flash_attention_softmax_n_amd import synth
         lib, fa = pkg._lib.load(), pkg.flash_attn
-        pkg.set_backward_plan(args.backward_plan)
         q, k, v = (synth.counter_normal((B, H, S, D), seed, dtype=dtype, device=dev) for seed in (101, 102, 103))
         do = synth.counter_normal((B, H, S, D), 104, std=1.0, dtype=dtype, device=dev)
         bias = mask = None
@@ -282,8 +313,8 @@ def main():
         fa._fill_fwd(bargs.fwd, q, k, v, o_s, lse, m8, b4, n, 1.0 / D ** 0.5, causal)
         bargs.dout, bargs.dq, bargs.dk, bargs.dv = (fa._view4(t) for t in (do, dq, dk, dv))
         bargs.delta = delta.data_ptr()
-        bargs.flags = pkg._lib.FASN_BWD_ONE_PASS if args.backward_plan == "one_pass" else 0
-        ws_bytes = lib.fasn_bwd_workspace_bytes(bargs)   # > 0: the one-pass plan applies; its fp32 dQ accumulator is the caller's
+        bargs.flags = 0
+        ws_bytes = lib.fasn_bwd_workspace_bytes(bargs)   # (0 with libfasn.so: the backward needs no scratch beyond delta)
         if ws_bytes:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             bargs.workspace, bargs.workspace_bytes = ws.data_ptr(), ws_bytes
@@ -322,7 +353,8 @@ def main():
         else:
             kernel_ms = kernel_time(raw["fwd"], 100) + kernel_time(raw["bwd"], 60)
 
-        dt = timed(ctl, steps_of[args.which], sync, args.steps, args.warmup)
+        tinfo = {}
+        dt = timed(ctl, steps_of[args.which], sync, args.steps, args.warmup, tinfo)
 
         def sample_under_load(fn, ms):
             """Clock / power under THIS load, AFTER everything that is timed: about 0.4 s of back-to-back launches, the amdgpu
@@ -349,30 +381,37 @@ def main():
         if args.which == "fwd" and args.workload == "m0" and world == 1 and not args.no_extra_passes:
             # driver-visible backward numbers next to the headline (same K and W, measured after the headline's timed region)
             for w in ("bwd", "fwdbwd"):
-                dtw = timed(ctl, steps_of[w], sync, args.steps, args.warmup)
+                winfo = {}
+                dtw = timed(ctl, steps_of[w], sync, args.steps, args.warmup, winfo)
                 kms = kernel_time(raw["bwd"], 60) if w == "bwd" else None
                 alg, exe = pass_flops(w, B, H, S, D, causal, vis)
                 extra["backward" if w == "bwd" else "fwdbwd"] = {
                     "steps_per_s": args.steps / dtw, "ms_per_step": dtw / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                    "timed_steps": winfo["timed_steps"],
                     "algorithmic_tflops": alg / (dtw / args.steps) / 1e12, "executed_tflops": exe / (dtw / args.steps) / 1e12,
                     "frac_of_peak_algorithmic": alg / (dtw / args.steps) / 1e12 / PEAK_TFLOPS,
                     **({"kernels_ms": kms, "kernels_frac_of_peak_executed": exe / (kms * 1e-3) / 1e12 / PEAK_TFLOPS} if kms else {})}
 
-        if rank == 0:
-            sample_under_load(raw[args.which] if args.which in raw else raw["bwd"], kernel_ms)
+        # every rank samples ITS GPU while all of them run the same loop: a bent 1 -> N curve can then be attributed from this one
+        # record (a shared power budget shows as lower clocks on all ranks, host launch contention as equal clocks and longer steps)
+        ctl.barrier()
+        sample_under_load(raw[args.which] if args.which in raw else raw["bwd"], kernel_ms)
 
+    mine = {"rank": rank, "ms_per_step": tinfo.get("local_ms_per_step")}
+    if not stub and sensors and sensors[0][0]:
+        mine["sclk_mhz"], mine["socket_power_w"] = sensors[0]
+    per_rank = ctl.gather(mine)
     if rank != 0:
         ctl.close()
         return
 
     ops_per_s = world * args.steps / dt
     alg, exe = pass_flops(args.which, B, H, S, D, causal, vis)
-    if args.backward_plan == "one_pass" and args.which != "fwd" and D == 64 and args.workload != "c1":
-        exe = alg   # the one-pass backward executes the 5 GEMMs of the algorithm
     names = {"fwd": "forward", "bwd": "backward", "fwdbwd": "forward+backward"}
     line = {
         "metric": f"attn-ops/sec (flash_attention_n {names[args.which]})", "value": ops_per_s, "unit": "attn-ops/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "timed_steps": tinfo.get("timed_steps", args.steps),   # the timed region: whole blocks of `steps` steps, at least 50 ms of work
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dname, "data": "synthetic",
         "config": {"workload": f"{args.workload}: flash_attention_n {args.which} (B={B},H={H},S={S},D={D}) n={n} causal={causal}"
                                + (" + ALiBi bias [H,L,S] + key-padding mask [B,1,1,S]" if args.workload == "c4" else ""),
@@ -380,25 +419,28 @@ def main():
                    "output_elements_per_s": ops_per_s * B * H * S * D,
                    "score_elements_per_s": ops_per_s * B * H * S * S * (0.5 if causal else 1.0)},
     }
+    if world > 1:
+        line["per_rank"] = per_rank   # each rank's own time per step and its GPU's clock / power under the common load
     if stub:
         line["data"] = "stub (no GPU work: launch + aggregation test)"
     else:
         achieved = alg / (kernel_ms * 1e-3) / 1e12
         line["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": pmc_traffic(args.workload + ("onepass" if args.backward_plan == "one_pass" and args.which != "fwd" else ""), args.which), "kernel_ms": kernel_ms,
-            "kernels": {"fwd": "fasn_fwd_kernel", "bwd": "fasn_bwd_delta + fasn_bwd_dq + fasn_bwd_dkdv", "fwdbwd": "fasn_fwd_kernel + the three backward kernels"}[args.which],
+            "traffic": pmc_traffic(args.workload, args.which), "kernel_ms": kernel_ms,
+            "kernels": {"fwd": "fasn_fwd_kernel", "bwd": "fasn_bwd_delta + dQ kernel + dK/dV kernel (D = 64 plain / causal: fasn_bwd_dq_pipe + fasn_bwd_dkdv_pipe)",
+                        "fwdbwd": "fasn_fwd_kernel + the three backward kernels"}[args.which],
             "algorithmic_flops_per_launch": alg, "executed_flops_per_launch": exe,
             "gemm_equivalents": {"algorithmic": (GEMMS256 if D > 128 else GEMMS)[args.which][0], "executed": (GEMMS256 if D > 128 else GEMMS)[args.which][1]},
             "frac_executed": exe / (kernel_ms * 1e-3) / 1e12 / peak,
-            **({"visible_key_tile_fraction": vis} if vis < 1.0 else {})}
+            # C4: `frac` divides SURVEY 8(d)'s dense-score count; the scores of padded keys are not needed by anybody, so the useful
+            # fraction is the one on visible keys (forward AND backward), the executed one follows the 64-key tiles that run
+            **({"visible_key_tile_fraction": vis, "visible_key_fraction": visk, "frac_on_visible_keys": achieved * visk / peak} if vis < 1.0 else {})}
         sm = [x for x in sensors if x[0]]
         if sm:   # nominal peak scaled to the clock the part held during the roofline loop (informative; `frac` stays against the nominal peak)
             mhz, watts = sm[0]
             line["roofline"]["under_load"] = {"sclk_mhz": mhz, "socket_power_w": watts, "nominal_mhz": 2400.0,
                                               "frac_of_clock_adjusted_peak": achieved / (peak * mhz / 2400.0)}
-        if args.backward_plan == "one_pass" and args.which != "fwd":
-            line["roofline"]["kernels"] = "fasn_bwd_delta + fasn_bwd_fused + fasn_bwd_dq_convert (one-pass plan)"
         line.update(extra)
 
     if not stub and world == 1 and not args.no_cpu_baseline:

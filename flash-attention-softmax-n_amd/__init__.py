@@ -7,7 +7,7 @@ Every function runs on device tensors through libfasn.so; importing the package 
 library raises ImportError (no silent fallback).
 """
 from . import _lib, dropout, statistics, surgery
-from .flash_attn import flash_attention_n, flash_attention_n_triton, set_backward_plan, slow_attention_n
+from .flash_attn import flash_attention_n, flash_attention_n_triton, slow_attention_n
 from .softmax import softmax_n
 
 _lib.load()  # fail loudly at import if the HIP extension is missing
@@ -15,4 +15,4 @@ _lib.load()  # fail loudly at import if the HIP extension is missing
 TRITON_INSTALLED = False  # kept for source compatibility: the Triton path is replaced by the HIP kernel
 HIP_NATIVE = True
 
-__all__ = ["flash_attention_n", "flash_attention_n_triton", "slow_attention_n", "softmax_n", "set_backward_plan", "TRITON_INSTALLED", "HIP_NATIVE"]
+__all__ = ["flash_attention_n", "flash_attention_n_triton", "slow_attention_n", "softmax_n", "TRITON_INSTALLED", "HIP_NATIVE"]

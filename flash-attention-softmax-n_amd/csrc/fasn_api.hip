@@ -309,13 +309,19 @@ int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int varian
 }
 #endif
 
-// One-pass backward (fasn_bwd_fused.h): opt-in (it measures slower than the split kernels), and only where it exists
+// One-pass backward (fasn_bwd_fused.h): a measured loser on MI355X, kept in the DEVELOPER library only
+// (tools/libfasn_dev.so, FASN_DEV_VARIANTS) for A/B work; libfasn.so ignores FASN_BWD_ONE_PASS and never asks for a workspace.
 static bool bwd_fused_applies(const fasn_bwd_args* a, const FwdParams& p, const FwdLaunch& l) {
+#ifndef FASN_DEV_VARIANTS
+    (void)a; (void)p; (void)l;
+    return false;
+#else
     if (!(a->flags & FASN_BWD_ONE_PASS)) return false;
     if (l.dtype == FASN_DTYPE_F32 || l.D != 64) return false;
     if (l.mode != MODE_PLAIN && l.mode != MODE_CAUSAL) return false;
     if (p.drop_thr != 0 || p.kvg > 1) return false;
     return true;
+#endif
 }
 static size_t bwd_fused_bytes(const fasn_bwd_args* a) { return (size_t)a->fwd.B * a->fwd.H * a->fwd.Sq * a->fwd.D * sizeof(float); }
 

@@ -10,8 +10,10 @@ int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
 #ifdef FASN_DEV_VARIANTS
     if (((FASN_BWD_VARIANT >> 8) & 3) && l.mode == MODE_PLAIN && l.dtype == 1) return launch_bwd_d64_exp(p, (FASN_BWD_VARIANT >> 8) & 3, s);
 #endif
-    if (p.dqacc != nullptr)   // fasn_api.hip sets the accumulator only where the one-pass backward applies (plain / causal, no dropout, no GQA)
+#ifdef FASN_DEV_VARIANTS
+    if (p.dqacc != nullptr)   // developer library: fasn_api.hip sets the accumulator only where the one-pass backward applies
         return launch_bwd_fused_d64(p, l, s);
+#endif
     // plain / causal without dropout or grouped K/V: the software-pipelined kernels of fasn_bwd_pipe.h
     // (developer library: bwd_variant bit 6 / bit 7 = the round-3 dK/dV / dQ kernel instead, for same-box A/B)
     BwdParams q = p;

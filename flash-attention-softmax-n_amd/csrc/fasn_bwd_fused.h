@@ -18,8 +18,10 @@
 //   tools/ubench_atomic.cpp; one partial per element and 512-key block: Sk/512 x |dQ| x 4 bytes per launch).
 //
 // fasn_bwd_dq_convert_kernel rounds the accumulator to the output type. The order of the atomic adds is not fixed, so dQ is
-// reproducible only to fp32 rounding of a sum of Sk/512 terms (dK / dV are deterministic): callers that need bit-exact
-// reruns set FASN_BWD_DETERMINISTIC and get the split kernels.
+// reproducible only to fp32 rounding of a sum of Sk/512 terms (dK / dV are deterministic).
+// DEVELOPER LIBRARY ONLY (round 4): the kernel lost to the split kernels in every build (1.92 - 2.3 ms against 1.75 - 1.8 ms at
+// (8,16,4096,64)), so libfasn.so no longer contains it; tools/libfasn_dev.so (FASN_DEV_VARIANTS) keeps it for A/B work behind
+// FASN_BWD_ONE_PASS in fasn_bwd_args.flags, the split kernels being the default there as well.
 //
 // Schedule: one barrier per tile; every wave runs [dQ GEMM of tile t-1] [S, dP, element pass, dS -> LDS] [dV, dK] on tile t.
 // (Measured and rejected: a ping-pong of the two waves of a SIMD - waves 0-3 in the S / dP / element phase while waves 4-7

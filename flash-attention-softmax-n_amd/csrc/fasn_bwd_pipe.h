@@ -698,8 +698,7 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dkdv_pipe2_kernel(const BwdPa
 //   phase A(j):  MFMA  S(j) (4)              | VALU  dS = p * dP', 16-bit conversion of block j-1   | LDS  K^T fragments of block j-1
 //   phase B(j):  MFMA  dP(j) (4), G(j-1) (4) | VALU  p = exp2(S') of block j                        | LDS  K / V row fragments of block j+1
 // The -LSE*log2e / -delta seeds are per-lane splats used as the untied C operand of the first MFMA of each chain. The causal
-// diagonal zeroes hidden P in a small wave-uniform branch between B and A. Keys past Sk need no test: their K rows read back as
-// zeros, so whatever dS they get adds nothing to dQ.
+// diagonal and the ragged last key tile zero hidden P in a small wave-uniform branch between B and A.
 constexpr int pipe_dq_smem_bytes() { return 2 * PNB * KT * 64 * 2; }
 
 template <typename Tag, int MODE>
@@ -862,12 +861,14 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
     };
     const int vis = row + coff;               // last key this lane's row sees (causal)
     const int wave_first_vis = qw0 + coff;    // ... the wave's first row sees
-    auto diag_mask = [&](f32x16& s, int k0) __attribute__((always_inline)) {   // zero the hidden P of a block on the causal diagonal
-        if (causal && (k0 + 31) > wave_first_vis) {
+    // zero the hidden P of a block on the causal diagonal or at the ragged end of the key range (K rows past Sk normally read back as
+    // zeros and would add nothing - but a ONE-key K has row stride 0 in the ABI's broadcast convention, so its tile rows all alias key 0)
+    auto diag_mask = [&](f32x16& s, int k0) __attribute__((always_inline)) {
+        if ((causal && (k0 + 31) > wave_first_vis) || k0 + 32 > p.Sk) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                s[r] = key <= vis ? s[r] : 0.f;
+                s[r] = (key < p.Sk && (!causal || key <= vis)) ? s[r] : 0.f;
             }
         }
     };

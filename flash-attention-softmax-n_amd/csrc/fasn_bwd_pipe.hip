@@ -34,6 +34,7 @@ int launch_bwd_dq_pipe_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s
     return l.dtype == 1 ? launch_dq_pipe<bf16_tag, MODE_PLAIN>(p, s) : launch_dq_pipe<f16_tag, MODE_PLAIN>(p, s);
 }
 
+#ifdef FASN_DEV_VARIANTS   // one wave per SIMD, 64 keys per wave: measured slower (1241 against 1031 us at M0), developer library only
 template <typename Tag, int MODE, int KB>
 static int launch_dkdv_pipe2(BwdParams p, hipStream_t s) {
     constexpr int BN = 4 * KB * 32;
@@ -50,6 +51,7 @@ int launch_bwd_dkdv_pipe2_d64(const BwdParams& p, const FwdLaunch& l, hipStream_
     if (l.mode == MODE_CAUSAL) return l.dtype == 1 ? launch_dkdv_pipe2<bf16_tag, MODE_CAUSAL, 2>(p, s) : launch_dkdv_pipe2<f16_tag, MODE_CAUSAL, 2>(p, s);
     return l.dtype == 1 ? launch_dkdv_pipe2<bf16_tag, MODE_PLAIN, 2>(p, s) : launch_dkdv_pipe2<f16_tag, MODE_PLAIN, 2>(p, s);
 }
+#endif
 
 int launch_bwd_dkdv_pipe_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.mode == MODE_CAUSAL) return l.dtype == 1 ? launch_dkdv_pipe<bf16_tag, MODE_CAUSAL>(p, s) : launch_dkdv_pipe<f16_tag, MODE_CAUSAL>(p, s);

@@ -79,9 +79,15 @@ def _next_rng_state(device):
         gen = torch.cuda.default_generators[idx]
         seed, off = gen.initial_seed(), gen.get_offset()
         gen.set_offset(off + 4)
-        if st is None or st["seed"] != seed:   # first use, or the generator was re-seeded: (re)create the graph stream
+        if st is None or st["seed"] != seed:   # first use, or the generator was re-seeded: (re)start the graph stream
             signed = seed - (1 << 64) if seed >= (1 << 63) else seed
-            _RNG_STATE[idx] = {"seed": seed, "state": torch.tensor([signed, _GRAPH_STREAM_BIT + off], dtype=torch.int64, device=device)}
+            fresh = torch.tensor([signed, _GRAPH_STREAM_BIT + off], dtype=torch.int64)
+            if st is None:
+                _RNG_STATE[idx] = {"seed": seed, "state": fresh.to(device)}
+            else:   # IN PLACE: a HIP graph captured earlier holds this tensor's address (fasn_rng_advance adds to it at every replay);
+                    # a new allocation would leave that graph writing into memory the caching allocator hands out again
+                st["state"].copy_(fresh)
+                st["seed"] = seed
         return seed & 0xFFFFFFFFFFFFFFFF, off & 0xFFFFFFFFFFFFFFFF
     if st is None:
         raise RuntimeError("dropout inside a HIP graph capture: run one dropout call on this device before capturing "
@@ -118,21 +124,6 @@ def _fill_fwd(a: FwdArgs, q, k, v, o, lse, mask, bias, n, scale, causal, dropout
         a.rng_state = None if rng is None else rng.data_ptr()
 
 
-_BACKWARD_PLAN = "split"
-
-
-def set_backward_plan(plan: str) -> str:
-    """Select the backward plan of fasn_bwd: "split" (default: dQ kernel + dK/dV kernel, 7 GEMMs, deterministic) or "one_pass"
-    (one kernel, 5 GEMMs, dQ accumulated with fp32 atomics - the structure of the reference's flash_attn_triton.py:199-226; exists
-    for D = 64 without mask / bias / dropout / grouped K/V, falls back to "split" elsewhere; measured slower on MI355X).
-    Returns the previous plan."""
-    global _BACKWARD_PLAN
-    if plan not in ("split", "one_pass"):
-        raise ValueError('plan must be "split" or "one_pass"')
-    prev, _BACKWARD_PLAN = _BACKWARD_PLAN, plan
-    return prev
-
-
 # ---- host path: one planned ABI call per pass, argument blocks cached per call signature -------------------------------------
 # Filling a ctypes struct costs ~0.15 us per field and a fasn_*_workspace_bytes() round trip ~2 us; both depend only on shapes,
 # strides, dtype and the scalar arguments. They are computed once per distinct signature (per thread: the cached block is
@@ -161,8 +152,8 @@ class _Plan:
 _WARNED_SLOW = set()
 
 
-def _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p, one_pass):
-    key = (_sig(q), _sig(k), _sig(v), _sig(mask), _sig(bias), n, scale, causal, dropout_p, one_pass, q.device.index)
+def _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p):
+    key = (_sig(q), _sig(k), _sig(v), _sig(mask), _sig(bias), n, scale, causal, dropout_p, q.device.index)
     c = _cache()
     pl = c.get(key)
     if pl is None:
@@ -179,10 +170,10 @@ def _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p, one_pass):
         _fill_fwd(pl.bwd.fwd, q, k, v, o, lse, mask, bias, n, scale, causal, dropout_p)
         dk = torch.empty((B, k.shape[1], k.shape[2], k.shape[3]), dtype=q.dtype, device=q.device)   # contiguous outputs: only the strides matter here
         pl.bwd.dout, pl.bwd.dq, pl.bwd.dk, pl.bwd.dv = _view4(o), _view4(o), _view4(dk), _view4(dk)
-        pl.bwd.flags = _lib.FASN_BWD_ONE_PASS if one_pass else 0
+        pl.bwd.flags = 0
         with torch.cuda.device(q.device):
             pl.fwd_ws = lib.fasn_fwd_workspace_bytes(pl.fwd)     # > 0: short-query / long-key shape, keys split over workgroups
-            pl.bwd_ws = lib.fasn_bwd_workspace_bytes(pl.bwd)     # > 0: one-pass backward, the fp32 dQ accumulator is ours to provide
+            pl.bwd_ws = lib.fasn_bwd_workspace_bytes(pl.bwd)     # 0 with libfasn.so (the ABI keeps the hook for plans that need scratch)
             pl.path = lib.fasn_fwd_path(pl.fwd)
         if pl.path == _lib.FASN_PATH_ELEMENT:   # same results, 3-5 x slower: say so once per kind of call instead of silently
             why = (_sig(mask), _sig(bias), dropout_p > 0.0)
@@ -211,7 +202,7 @@ def _launch_fwd(q, k, v, mask, bias, n, scale, causal, dropout_p, rng):
     B, H, L, _ = q.shape
     o = torch.empty((B, H, L, v.shape[3]), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
-    pl = _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p, _BACKWARD_PLAN == "one_pass")
+    pl = _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p)
     a = pl.fwd
     a.q.ptr, a.k.ptr, a.v.ptr, a.o.ptr, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
     if mask is not None:
@@ -273,10 +264,7 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
         delta = torch.empty((B, H, L), dtype=torch.float32, device=dev)
         if _POISON_SCRATCH:   # tests: every kernel that reads delta must find it written (by fasn_bwd_delta or the dQ kernel's prologue)
             delta.fill_(float("nan"))
-        # plan: split kernels (default, deterministic) or the opt-in one-pass backward (fp32 atomics for dQ; never under
-        # torch.use_deterministic_algorithms(True)) - see set_backward_plan()
-        one_pass = _BACKWARD_PLAN == "one_pass" and not torch.are_deterministic_algorithms_enabled()
-        pl = _plan_for(q, k, v, mask, bias, ctx.n, ctx.scale, ctx.causal, ctx.dropout_p, one_pass)
+        pl = _plan_for(q, k, v, mask, bias, ctx.n, ctx.scale, ctx.causal, ctx.dropout_p)
         a = pl.bwd
         f = a.fwd
         f.q.ptr, f.k.ptr, f.v.ptr, f.o.ptr, f.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
@@ -306,13 +294,16 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
                 a.dbias = _view4(dbias)
         else:
             a.dbias.ptr = None
-        with torch.cuda.device(dev):
-            if pl.bwd_ws:
-                ws = torch.empty(pl.bwd_ws, dtype=torch.uint8, device=dev)
-                a.workspace, a.workspace_bytes = ws.data_ptr(), pl.bwd_ws
-            _lib.check(lib.fasn_bwd(a, _stream_ptr(dev)), "fasn_bwd")
-        if dout.stride() != o.stride():
-            a.dout = _view4(o)   # restore the cached block's default strides
+        try:
+            with torch.cuda.device(dev):
+                if pl.bwd_ws:
+                    ws = torch.empty(pl.bwd_ws, dtype=torch.uint8, device=dev)
+                    a.workspace, a.workspace_bytes = ws.data_ptr(), pl.bwd_ws
+                _lib.check(lib.fasn_bwd(a, _stream_ptr(dev)), "fasn_bwd")
+        finally:   # the block is cached per call signature: whatever this call changed beyond pointers goes back, also when the launch raised
+            if dout.stride() != o.stride():
+                a.dout = _view4(o)
+            a.dbias.ptr = None
         if dbias is not None and dbias.dtype != bias.dtype:
             dbias = dbias.to(bias.dtype)
         return dq, dk, dv, None, dbias, None, None, None, None, None, None
@@ -322,7 +313,9 @@ def _pad_feature(t: Tensor, d: int) -> Tensor:
     return t if t.shape[-1] == d else torch.nn.functional.pad(t, (0, d - t.shape[-1]))
 
 
-def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) -> Tensor:
+def _prepare(query, key, value, n, scale, dropout_p, mask, bias):
+    """Argument normalisation shared by flash_attention_n and kernel_path: validation, K/V head expansion, sign of the scale, feature
+    padding, row alignment, mask / bias broadcasting. Returns (q, k, v, mask, bias, n, scale, dropout_p, dpad, Ev, bias_small)."""
     if not query.is_cuda:
         raise RuntimeError("flash_attention_softmax_n_amd runs on MI355X device tensors only; got a CPU tensor "
                            "(there is deliberately no CPU fallback)")
@@ -389,17 +382,24 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
         if bias.dtype not in (query.dtype, torch.float32):
             bias = bias.to(query.dtype)
         # a bias that needs a gradient and broadcasts over batch and / or heads only ([H,L,S], [1,H,L,S], [B,1,L,S], [1,1,L,S]) keeps
-        # its own shape: fasn_bwd then returns the gradient already summed over those dimensions (csrc/fasn_bwd_dbias.h)
+        # its own shape: fasn_bwd then returns the gradient already summed over those dimensions (csrc/fasn_bwd_dbias.h).
+        # (L == 1 stays on the dense path: a one-row bias is also a ROW broadcast, whose stride 0 the reduced form rejects)
         bias_small = (bias.requires_grad and torch.is_grad_enabled() and dropout_p == 0.0 and query.dtype != torch.float32
-                      and bias.shape[2] == L and bias.shape[3] == S and bias.shape[0] in (1, B) and bias.shape[1] in (1, H)
+                      and L > 1 and bias.shape[2] == L and bias.shape[3] == S and bias.shape[0] in (1, B) and bias.shape[1] in (1, H)
                       and ((bias.shape[0] == 1 and B > 1) or (bias.shape[1] == 1 and H > 1)) and bias.stride(3) == 1)
         if not bias_small:
             bias = bias.expand(B, H, L, S)
-
-    # dropout: this call's (seed, offset) (see _next_rng_state); the kernels derive every keep/drop bit from
-    # (seed, offset, b, h, row, key) - dropout.py is the host mirror
     if bias is None:
         bias_small = False
+    return q, k, v, mask, bias, n, scale, dropout_p, dpad, Ev, bias_small
+
+
+def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) -> Tensor:
+    q, k, v, mask, bias, n, scale, dropout_p, dpad, Ev, bias_small = _prepare(query, key, value, n, scale, dropout_p, mask, bias)
+    B, H, L, _ = q.shape
+    S = k.shape[2]
+    # dropout: this call's (seed, offset) (see _next_rng_state); the kernels derive every keep/drop bit from
+    # (seed, offset, b, h, row, key) - dropout.py is the host mirror
     rng = _next_rng_state(query.device) if dropout_p > 0.0 else None
     _TLS.last_rng_state = rng   # per thread: what last_dropout_state() / last_rng_state() report
     Hkv = k.shape[1]
@@ -428,22 +428,12 @@ def kernel_path(query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[T
                 is_causal: bool = False, dropout_p: float = 0.0, scale: Optional[float] = None) -> str:
     """Name of the kernel family a flash_attention_n call with these arguments is routed to (fasn_fwd_path): "plain", "key-padding",
     "vector mask/bias", "vector bias + key-padding", "element-load (slow)" or "fp32". Launches nothing."""
-    lib = _lib.load()
-    B, H, L, E = query.shape
-    S = key.shape[-2]
-    a = FwdArgs()
-    mask = None if attn_mask is None else attn_mask.expand(B, H, L, S).view(torch.uint8)
-    bias = attn_bias
-    if bias is not None:
-        bias = (bias.unsqueeze(0) if bias.dim() == 3 else bias).expand(B, H, L, S)
-    lse = torch.empty(0, device=query.device)
-    _fill_fwd(a, query, key if key.dim() == 4 else key.unsqueeze(1), value if value.dim() == 4 else value.unsqueeze(1), query, lse, mask, bias, 1.0,
-              (1.0 / sqrt(E)) if scale is None else float(scale), bool(is_causal), float(dropout_p))
-    a.lse = None
-    rc = lib.fasn_fwd_path(a)
-    if rc < 0:
-        _lib.check(rc, "fasn_fwd_path")
-    return _lib.FASN_PATH_NAMES[rc]
+    q, k, v, mask, bias, n, sc, dp, _, _, bias_small = _prepare(query, key, value, 1.0, scale, dropout_p, attn_mask, attn_bias)
+    if bias_small:
+        bias = bias.expand(q.shape[0], q.shape[1], q.shape[2], k.shape[2])
+    # the plan of exactly the call flash_attention_n would make (same canonical tensors, same cache); fasn_fwd_path looks at layout
+    # and modes only, so the placeholder n = 1 does not matter
+    return _lib.FASN_PATH_NAMES[_plan_for(q, k, v, mask, bias, n, sc, bool(is_causal), dp).path]
 
 
 def last_rng_state():

@@ -39,11 +39,11 @@ extern "C" {
 #define FASN_OK 0
 #define FASN_EINVAL (-1)      /* NULL pointer / non-positive size / bad enum */
 #define FASN_EDTYPE (-2)      /* unsupported element type */
-#define FASN_EHEADDIM (-3)    /* unsupported head dimension (supported: 32, 64, 128; D == Dv) */
+#define FASN_EHEADDIM (-3)    /* unsupported head dimension (supported: 32, 64, 128 and - fp16 / bf16 - 256; D == Dv) */
 #define FASN_EALIGN (-4)      /* pointer or stride breaks the 16-byte row alignment rule */
 #define FASN_ESTRIDE (-5)     /* feature stride != 1 */
 #define FASN_ELAUNCH (-6)     /* hipLaunchKernel / hipGetLastError failure */
-#define FASN_EUNSUPPORTED (-7)/* valid request this build does not implement (e.g. dropout) */
+#define FASN_EUNSUPPORTED (-7)/* valid request this build does not implement (e.g. a reduced bias gradient with fp32 q/k/v or dropout) */
 #define FASN_EWORKSPACE (-8)  /* workspace missing or too small */
 
 /* element types of q/k/v/o/do/dq/dk/dv (FASN_DTYPE_F32 = 2, defined below: exact-fp32 MFMA kernels; with fp32 q/k/v the
@@ -102,17 +102,13 @@ typedef struct fasn_fwd_args {
  * dq/dk/dv are written (not accumulated) in `dtype`. `delta` is a [B,H,Sq] fp32 scratch the
  * caller provides.
  *
- * Two plans. (1) Split (the default; deterministic): a dQ kernel and a dK/dV kernel that each recompute S and dP, 7 GEMMs for
- * the 5 of the algorithm, no workspace. (2) One pass (ABI 4, opt-in with FASN_BWD_ONE_PASS in `flags`; D = 64, fp16 / bf16,
- * no mask / bias / dropout / grouped K/V): the dK/dV workgroups also form dQ = dS K per score block - 5 GEMMs, the structure
- * of the reference's single kernel (flash_attn_triton.py:199-226) - and add their partial dQ tiles into an fp32 accumulator
- * [B,H,Sq,D] with hardware atomics (the reference's load-add-store at :223-226); a last pass rounds it to `dtype`. The
- * accumulator is the caller's `workspace`: fasn_bwd_workspace_bytes() returns its size when plan (2) is requested and
- * applies to `args` (else 0); a NULL or too small workspace silently selects plan (1). With plan (2) dQ is reproducible to
- * fp32 rounding of a sum of ceil(Sk/512) terms, not bit for bit; dK and dV are deterministic in both plans. Plan (2) is
- * NOT the default because it measures slower on MI355X (1.92 against 1.78 ms at (8,16,4096,64)).
+ * Plan: a dQ kernel and a dK/dV kernel that each recompute S and dP (7 GEMMs for the 5 of the algorithm, deterministic, no
+ * workspace). The single 5-GEMM kernel of the reference (flash_attn_triton.py:199-226; dQ by load-add-store, here fp32 atomics
+ * into a caller-provided accumulator) was built in round 3 and measured slower on MI355X in every form:
+ * since round 4 only the developer library carries it. libfasn.so ignores FASN_BWD_ONE_PASS, fasn_bwd_workspace_bytes() returns 0
+ * and `workspace` may be NULL; the fields stay in the struct so that the ABI version does not change.
  */
-#define FASN_BWD_ONE_PASS 1 /* fasn_bwd_args.flags: take the one-pass backward where it exists */
+#define FASN_BWD_ONE_PASS 1 /* fasn_bwd_args.flags: reserved (one-pass backward: developer library only); ignored by libfasn.so */
 typedef struct fasn_bwd_args {
     fasn_fwd_args fwd; /* same views as forward; o and lse are inputs here */
     fasn_view4 dout;   /* [B,H,Sq,Dv] */

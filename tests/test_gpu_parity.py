@@ -291,78 +291,49 @@ def test_golden_g5f_backward_at_full_grid(pkg, dev, golden_dir, cfg):
             assert err <= lim, f"{cfg} head {hi} {name}: max-abs {err:.3e} vs fp32 slow_attention_n > {lim:.3e}"
 
 
-# ---------------------------------------------------------------- the opt-in one-pass backward (5 GEMMs, dQ by fp32 atomics)
-@pytest.fixture
-def one_pass_plan(pkg):
-    prev = pkg.set_backward_plan("one_pass")
-    yield
-    pkg.set_backward_plan(prev)
-
-
-@pytest.mark.parametrize("cfg", ["c2", "c3", "m0", "c5"])
-def test_golden_g5f_backward_one_pass_plan(pkg, dev, golden_dir, one_pass_plan, cfg):
-    """The D = 64 BASELINE configs at their full grid through fasn_bwd's one-pass plan (csrc/fasn_bwd_fused.h; the structure of the
-    reference's single backward kernel, flash_attn_triton.py:199-226): same fixtures and the same two gates as the split plan."""
-    test_golden_g5f_backward_at_full_grid(pkg, dev, golden_dir, cfg)
+# ---------------------------------------------------------------- backward plan
+def test_backward_needs_no_workspace_and_ignores_the_reserved_flag(pkg, dev):
+    """libfasn.so has ONE backward plan (dQ kernel + dK/dV kernel, deterministic): fasn_bwd_workspace_bytes is 0 whatever `flags` says
+    (the one-pass 5-GEMM kernel lives in the developer library only since round 4) and two runs agree bit for bit"""
+    from flash_attention_softmax_n_amd import _lib
+    from flash_attention_softmax_n_amd.flash_attn import _fill_fwd, _view4
+    lib = _lib.load()
+    q = torch.zeros(1, 2, 64, 64, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(1, 2, 64, dtype=torch.float32, device=dev)
+    a = _lib.BwdArgs()
+    _fill_fwd(a.fwd, q, q, q, q, lse, None, None, 1.0, 0.125, False)
+    a.dout = a.dq = a.dk = a.dv = _view4(q)
+    for flags in (0, _lib.FASN_BWD_ONE_PASS):
+        a.flags = flags
+        assert lib.fasn_bwd_workspace_bytes(a) == 0
+    qq, kk, vv = (_rand((2, 4, 1100, 64), torch.bfloat16, dev, s).requires_grad_() for s in (1, 2, 3))
+    do = _rand((2, 4, 1100, 64), torch.bfloat16, dev, 4, std=1.0)
+    grads = []
+    for _ in range(2):
+        qq.grad = kk.grad = vv.grad = None
+        pkg.flash_attention_n(qq, kk, vv, softmax_n_param=1.0, is_causal=True).backward(do)
+        grads.append([g.clone() for g in (qq.grad, kk.grad, vv.grad)])
+    for g0, g1 in zip(*grads):
+        assert torch.equal(g0, g1)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("L,S", [(1024, 1024), (100, 77), (3, 5), (300, 200), (1100, 1300), (1300, 1100), (33, 1000), (513, 1537)])
-def test_one_pass_plan_vs_oracle_and_split(pkg, dev, one_pass_plan, L, S, causal, dtype):
-    """Ragged sizes, L != S (bottom-right causal alignment), several 512-key blocks per head, n in {0, 1}: the one-pass plan against
-    the oracle, and its dQ against the split plan's (they may differ by fp32 summation order only: far below one 16-bit ulp)."""
-    B, H, D = 2, 2, 64
-    n = 1.0 if (L % 2 or L > S) else 0.0   # (n = 0 with fully hidden rows, causal L > S: the oracle's autograd is 0/0 there)
-    q, k, v = (_rand((B, H, s_, D), dtype, dev, sd).requires_grad_() for s_, sd in ((L, 11), (S, 12), (S, 13)))
-    do = _rand((B, H, L, D), dtype, dev, 14, std=1.0)
+@pytest.mark.parametrize("L,S", [(1024, 1024), (100, 77), (3, 5), (300, 200), (1100, 1300), (1300, 1100), (33, 1000), (513, 1537), (64, 1), (1, 64), (129, 127)])
+def test_pipelined_backward_ragged_sizes(pkg, dev, L, S, causal, dtype):
+    """the software-pipelined D = 64 dQ / dK/dV kernels (csrc/fasn_bwd_pipe.h: plain and causal launches): ragged tiles, L != S
+    (bottom-right causal alignment), query tiles that see no key, one-block launches, n in {0, 1}"""
+    n = 1.0 if (L % 2 or L > S) else 0.0   # (n = 0 with fully hidden rows - causal L > S - is 0/0 in the oracle's autograd)
+    B, H, D = 2, 3, 64
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
     out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal)
     out.backward(do)
-    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=n, is_causal=causal)
-    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
-        _check(got, want, dtype, f"one-pass {nm}")
-    one = [t.grad.clone() for t in (q, k, v)]
-    pkg.set_backward_plan("split")
-    for t in (q, k, v):
-        t.grad = None
-    pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=causal).backward(do)
-    assert torch.equal(one[1], k.grad) or (one[1].float() - k.grad.float()).abs().max() <= REL_TRUE[dtype] * k.grad.float().abs().max()
-    ulp = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * max(q.grad.float().abs().max().item(), 1e-3)
-    assert (one[0].float() - q.grad.float()).abs().max().item() <= 2 * ulp
+    _, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=n, is_causal=causal)
+    for got, want, nm in ((q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"{nm} L{L} S{S} causal{causal}")
 
 
-def test_one_pass_plan_is_opt_in_and_falls_back(pkg, dev):
-    """Default plan = split (no workspace asked for); the one-pass plan exists for D = 64 plain / causal only and everything else
-    (other head dims, masks, bias, dropout, grouped K/V, deterministic mode) silently takes the split kernels."""
-    from flash_attention_softmax_n_amd import _lib
-    from flash_attention_softmax_n_amd.flash_attn import BwdArgs, _fill_fwd
-    lib = _lib.load()
-
-    def ws_bytes(D, flags, mask=None, Hkv=2):
-        q = torch.zeros(1, 2, 64, D, dtype=torch.bfloat16, device=dev)
-        k = torch.zeros(1, Hkv, 64, D, dtype=torch.bfloat16, device=dev)
-        lse = torch.zeros(1, 2, 64, dtype=torch.float32, device=dev)
-        a = BwdArgs()
-        _fill_fwd(a.fwd, q, k, k, q, lse, mask, None, 1.0, 0.125, False)
-        a.flags = flags
-        return lib.fasn_bwd_workspace_bytes(a)
-
-    assert ws_bytes(64, 0) == 0
-    assert ws_bytes(64, _lib.FASN_BWD_ONE_PASS) == 1 * 2 * 64 * 64 * 4
-    assert ws_bytes(128, _lib.FASN_BWD_ONE_PASS) == 0 and ws_bytes(32, _lib.FASN_BWD_ONE_PASS) == 0
-    assert ws_bytes(64, _lib.FASN_BWD_ONE_PASS, Hkv=1) == 0
-    m = torch.ones(1, 2, 64, 64, dtype=torch.uint8, device=dev)
-    assert ws_bytes(64, _lib.FASN_BWD_ONE_PASS, mask=m) == 0
-    prev = pkg.set_backward_plan("one_pass")
-    try:
-        q, k, v = (_rand((1, 2, 128, 128), torch.bfloat16, dev, s).requires_grad_() for s in (1, 2, 3))
-        pkg.flash_attention_n(q, k, v, softmax_n_param=1.0).sum().backward()   # D = 128: split kernels
-        assert torch.isfinite(q.grad.float()).all()
-    finally:
-        pkg.set_backward_plan(prev)
-
-
-# ---------------------------------------------------------------- head dims above 128 (the reference API serves any E through SDPA)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["plain", "causal", "bias", "keypad+causal"])
 @pytest.mark.parametrize("shape", [(2, 8, 1024, 1024, 256), (1, 2, 200, 333, 160), (2, 2, 77, 100, 192), (1, 1, 3, 5, 256)])
@@ -1061,6 +1032,88 @@ def test_attn_bias_gradient(pkg, dev, D, kind, dtype):
     else:
         for got, want, nm in ((out, o, "out"), (q.grad, qc.grad, "dq"), (k.grad, kc.grad, "dk"), (bias.grad, bc.grad, "dbias")):
             _check(got, want, dtype, f"{kind}/{nm}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", ["1h1s", "b11s", "h1s"])
+def test_attn_bias_gradient_with_one_query_row(pkg, dev, shape, dtype):
+    """L == 1 with a differentiable bias that broadcasts over batch / heads: a one-row bias is also a row broadcast, which the in-kernel
+    reduced form does not serve - the call has to take the dense dS path (round-3 regression: FASN_EUNSUPPORTED in backward)"""
+    B, H, L, S, D = 3, 4, 1, 333, 64
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    gen = torch.Generator().manual_seed(5)
+    bshape = {"1h1s": (1, H, 1, S), "b11s": (B, 1, 1, S), "h1s": (H, 1, S)}[shape]
+    bias = torch.randn(*bshape, generator=gen).to(dtype).to(dev).requires_grad_()
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, attn_bias=bias)
+    out.backward(do)
+    assert bias.grad is not None and bias.grad.shape == bias.shape
+    qc, kc, vc, bc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v, bias))
+    o = ref_attention_n(qc, kc, vc, softmax_n_param=1.0, attn_bias=bc)
+    o.backward(do.cpu().float())
+    for got, want, nm in ((out, o, "out"), (q.grad, qc.grad, "dq"), (k.grad, kc.grad, "dk"), (bias.grad, bc.grad, "dbias")):
+        _check(got, want, dtype, f"{shape}/{nm}")
+
+
+def test_cached_argument_block_survives_a_failed_backward(pkg, dev, monkeypatch):
+    """the per-signature BwdArgs block is mutated in place for a non-default dO layout: when the launch raises, the default strides
+    must be back for the next call of the same signature (they used to be restored only after a successful launch)"""
+    from flash_attention_softmax_n_amd import _lib
+    dtype = torch.bfloat16
+    B, H, L, D = 1, 2, 128, 64
+    q, k, v = (_rand((B, H, L, D), dtype, dev, s).requires_grad_() for s in (1, 2, 3))
+    do = _rand((B, L, H, D), dtype, dev, 4, std=1.0).transpose(1, 2)   # [B,H,L,D] view of [B,L,H,D] memory: aligned rows, other strides
+    lib = _lib.load()
+    real = lib.fasn_bwd
+    calls = {"n": 0}
+
+    class Failing:
+        def __getattr__(self, name):
+            if name == "fasn_bwd":
+                def f(*a):
+                    calls["n"] += 1
+                    return -4 if calls["n"] == 1 else real(*a)
+                return f
+            return getattr(lib, name)
+    monkeypatch.setattr(_lib, "load", lambda: Failing())
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0)
+    with pytest.raises(Exception):
+        out.backward(do, retain_graph=True)
+    q.grad = k.grad = v.grad = None
+    out.backward(do.contiguous())   # default layout through the same cached block
+    _, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0)
+    for got, want, nm in ((q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, nm)
+
+
+def test_kernel_path_uses_the_arguments_of_the_real_call(pkg, dev):
+    """kernel_path() runs the same normalisation as flash_attention_n: padded head dims, 3-D keys, negative scales"""
+    from flash_attention_softmax_n_amd.flash_attn import kernel_path
+    q = torch.randn(2, 4, 100, 80, device=dev, dtype=torch.bfloat16)      # head dim 80 is zero-padded to 128 by the call
+    kv = torch.randn(2, 96, 80, device=dev, dtype=torch.bfloat16)          # 3-D key / value: shared by all heads
+    assert kernel_path(q, kv, kv) == "plain"
+    assert kernel_path(q, kv, kv, is_causal=True, scale=-0.2) == "plain"
+    m = torch.ones(2, 1, 1, 96, dtype=torch.bool, device=dev)
+    assert kernel_path(q, kv, kv, attn_mask=m) == "key-padding"
+    b = torch.randn(4, 100, 96, device=dev, dtype=torch.bfloat16)
+    assert kernel_path(q, kv, kv, attn_mask=m, attn_bias=b) == "vector bias + key-padding"
+    assert kernel_path(q, kv[:, :90], kv[:, :90], attn_bias=b[..., :90]) == "element-load (slow)"   # 180-byte bias rows are not 8-byte vectors
+    assert kernel_path(q.float(), kv.float(), kv.float()) == "fp32"
+
+
+def test_graph_dropout_state_keeps_its_address_across_reseeding(pkg, dev):
+    """the device {seed, offset} pair a captured graph advances is updated IN PLACE by torch.manual_seed + the next eager dropout
+    call: a graph captured before the re-seed must not be left with a dangling pointer"""
+    from flash_attention_softmax_n_amd import flash_attn as fa
+    q = _rand((1, 2, 64, 64), torch.bfloat16, dev, 1)
+    torch.manual_seed(11)
+    pkg.flash_attention_n(q, q, q, softmax_n_param=1.0, dropout_p=0.1)
+    st = fa._RNG_STATE[dev.index if dev.index is not None else 0]["state"]
+    ptr = st.data_ptr()
+    torch.manual_seed(12)
+    pkg.flash_attention_n(q, q, q, softmax_n_param=1.0, dropout_p=0.1)
+    st2 = fa._RNG_STATE[dev.index if dev.index is not None else 0]["state"]
+    assert st2.data_ptr() == ptr and int(st2.cpu()[0]) == 12
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -66,6 +66,20 @@ def test_bench_py_launches_its_own_two_replicas():
     t = line["ms_per_step"]                     # max over ranks = rank 1's 20 ms per step
     assert 19.0 <= t <= 40.0
     assert abs(line["value"] - 2 * 1e3 / t) < 1e-6 * line["value"]   # value = N * K / max-over-ranks(time of K steps)
+    # the timed region is whole blocks of K steps and at least 50 ms long (here one block: 5 steps of 20 ms); every rank's own time is reported
+    assert line["timed_steps"] % 5 == 0 and line["timed_steps"] * t >= 50.0
+    pr = line["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and 9.0 <= pr[0]["ms_per_step"] <= 20.0 and abs(pr[1]["ms_per_step"] - t) < 1e-6
+
+
+def test_bench_py_times_at_least_50_ms():
+    """K steps of 1 ms would be a 3 ms timed region: the region is repeated in whole blocks of K until it lasts >= 50 ms, `steps` stays K"""
+    r, lines = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--stub-step-ms", "1"],
+                           env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr
+    line = lines[0]
+    assert line["steps"] == 3 and line["timed_steps"] % 3 == 0 and line["timed_steps"] >= 30
+    assert line["timed_steps"] * line["ms_per_step"] >= 50.0 and "per_rank" not in line
 
 
 def test_bench_py_joins_a_launcher_world_and_refuses_a_mismatch():
