@@ -31,7 +31,12 @@ namespace fasn {
 #ifndef FASN_WS_ATTR
 #define FASN_WS_ATTR
 #endif
-template <typename Tag, int D, int MODE, int GQA = 0>   // GQA = 1: the loop over the query heads of a K/V group is compiled in
+// DROP = 1 (round 4): attention-weight dropout. Wave A draws the keep bits and publishes P with the sign bit set for a dropped weight
+// (see fasn_bwd_dq_ws.h); its own dV GEMM takes the kept weights only and the 1/(1-p) goes on the dV accumulator at the end. A lane
+// owns a KEY here and its registers are rows, so the (row, key quad) state the forward computes once per 4 weights would be needed once
+// per weight - but the four lanes of a key quad hold the same 16 rows: each computes the state of ONE row of a 4-row register group and
+// the quad exchanges them with DPP quad_perm moves (4 states instead of 16 per block and lane, the same bits as everywhere else).
+template <typename Tag, int D, int MODE, int GQA = 0, int DROP = 0>   // GQA = 1: the loop over the query heads of a K/V group is compiled in
 __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(const BwdParams bp) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -63,6 +68,8 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     const int hi = lane >> 5;
     const int role = wave >> 2;    // 0 = A (S, P, dV), 1 = B (dP, dS, dK)
     const int kbw = wave & 3;      // key block of this wave inside the workgroup's 128 keys
+    const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
+    static_assert(!(DROP && GQA), "dropout with grouped K/V stays on the one-wave kernel");
 
     // One workgroup per (batch, K/V head, 128-key block). Grouped-query attention (kvg query heads per K/V head): the workgroup
     // walks the q-tiles of ALL query heads of its group, one head after the other, into the same accumulators - dK / dV come out
@@ -137,6 +144,8 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     const int kw0 = kblk * BN + kbw * 32;   // first key of this wave
     const int key = kw0 + l31;
     const int coff = p.Sk - p.Sq;
+    const int bh_drop = b * p.H + h;        // (dropout instantiations: one query head per K/V head)
+    const DropLane dlane = drop_lane(key & 3);
 
     const char* kbase = p.k + (b * p.ks[0] + hk * p.ks[1]) * 2;
     const char* vbase = p.v + (b * p.vs[0] + hk * p.vs[1]) * 2;
@@ -348,9 +357,10 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
             }
         };
         auto soft = [&](int qb, const f32x16& sacc, vec8 (&pfr)[2], auto MASKED) {   // P = exp2(S'), packed, and published for wave B
+            vec8 pub[2];   // (DROP: what wave B gets - sign set on dropped weights; pfr keeps the kept weights for dV)
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
-                f32x8 x;
+                f32x8 x, xs;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int r = 8 * t2 + e;
@@ -361,13 +371,31 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
                         pv = show ? pv : 0.f;
                     }
                     x[e] = pv;
+                    xs[e] = pv;
+                    if (DROP) {
+                        // the state of (row, key quad): computed by the lane of the quad whose key & 3 equals the row's place in its
+                        // 4-row register group, fetched from it with a quad_perm broadcast (r & 3 is a compile-time constant here)
+                        const int g = r >> 2;
+                        const uint32_t own = drop_mix(drop_row_base(dsd.lo, (uint32_t)bh_drop, (uint32_t)(r0 + qb * 32 + 8 * g + 4 * hi + (lane & 3))), dsd.hi, (uint32_t)(key >> 2));   // (one per g: CSE)
+                        uint32_t hy;
+                        switch (r & 3) {   // quad_perm broadcast of lane (quad base + (r & 3))
+                            case 0: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0x00, 0xf, 0xf, false); break;
+                            case 1: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0x55, 0xf, 0xf, false); break;
+                            case 2: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xAA, 0xf, 0xf, false); break;
+                            default: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xFF, 0xf, 0xf, false); break;
+                        }
+                        const bool keep = drop_keep(drop_word(hy, dlane), p.drop_thr << 16);
+                        x[e] = keep ? pv : 0.f;
+                        xs[e] = keep ? pv : -pv;
+                    }
                 }
                 pfr[t2] = E::cvt8(x);
+                if (DROP) pub[t2] = E::cvt8(xs);
             }
             char* ps = pslot(pb, qb);   // lane to same lane, 2 x 16 bytes
             u32x4 w0, w1;
-            __builtin_memcpy(&w0, &pfr[0], 16);
-            __builtin_memcpy(&w1, &pfr[1], 16);
+            __builtin_memcpy(&w0, DROP ? &pub[0] : &pfr[0], 16);
+            __builtin_memcpy(&w1, DROP ? &pub[1] : &pfr[1], 16);
             if (KPD) {   // key padding: the lane's key is hidden for every row - clear its packed weights (also what dV multiplies)
                 const uint32_t kpm = kp_keep ? 0xffffffffu : 0u;
 #pragma unroll
@@ -375,8 +403,21 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
                     w0[e] &= kpm;
                     w1[e] &= kpm;
                 }
-                __builtin_memcpy(&pfr[0], &w0, 16);
-                __builtin_memcpy(&pfr[1], &w1, 16);
+                if (DROP) {   // (the kept weights of dV are a different pair of registers)
+                    u32x4 v0, v1;
+                    __builtin_memcpy(&v0, &pfr[0], 16);
+                    __builtin_memcpy(&v1, &pfr[1], 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v0[e] &= kpm;
+                        v1[e] &= kpm;
+                    }
+                    __builtin_memcpy(&pfr[0], &v0, 16);
+                    __builtin_memcpy(&pfr[1], &v1, 16);
+                } else {
+                    __builtin_memcpy(&pfr[0], &w0, 16);
+                    __builtin_memcpy(&pfr[1], &w1, 16);
+                }
             }
             *LDS_PTR(u32x4, ps) = w0;
             *LDS_PTR(u32x4, ps + 1024) = w1;
@@ -439,7 +480,7 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
             for (int g = 0; g < 4; ++g) {
                 const f32x4 c = *LDS_PTR(const f32x4, tX + qb * 32 + 8 * g + 4 * hi);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pacc[qb][4 * g + e] = c[e];
+                for (int e = 0; e < 4; ++e) pacc[qb][4 * g + e] = DROP ? 0.f : c[e];   // (dropout scales dP before delta is subtracted: dP starts at 0)
             }
             const char* ps = pslot(pb, qb);
             pw[qb][0] = *LDS_PTR(const u32x4, ps);
@@ -457,11 +498,21 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
                 f32x8 x;
+                f32x4 nd[2] = {};   // dropout: -delta of the rows of registers 8 t2 .. 8 t2 + 7, read again here instead of living in 32 registers
+                if (DROP) {
+                    nd[0] = *LDS_PTR(const f32x4, tX + qb * 32 + 8 * (2 * t2) + 4 * hi);
+                    nd[1] = *LDS_PTR(const f32x4, tX + qb * 32 + 8 * (2 * t2 + 1) + 4 * hi);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const uint32_t word = pw[qb][t2][e >> 1];
                     const float pv = E::to_f32((uint16_t)((e & 1) ? (word >> 16) : (word & 0xffffu)));
-                    x[e] = pv * pacc[qb][8 * t2 + e];
+                    if (DROP) {   // sign set = dropped weight
+                        const float dpe = __builtin_signbit(pv) ? 0.f : pacc[qb][8 * t2 + e] * p.drop_scale;
+                        x[e] = __builtin_fabsf(pv) * (dpe + nd[e >> 2][e & 3]);
+                    } else {
+                        x[e] = pv * pacc[qb][8 * t2 + e];
+                    }
                 }
                 dsf[qb][t2] = E::cvt8(x);
             }
@@ -545,7 +596,7 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     if (key < p.Sk) {
         char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + hk * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 2     // dK / dV are [B, H / kvg, Sk, D]
                              : bp.dk + (b * bp.dks[0] + hk * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
-        const float sc = role == 0 ? 1.0f : bp.scale;
+        const float sc = role == 0 ? (DROP ? p.drop_scale : 1.0f) : bp.scale;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll

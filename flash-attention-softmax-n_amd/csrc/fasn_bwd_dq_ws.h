@@ -20,7 +20,11 @@ namespace fasn {
 
 constexpr int kDqWsMaxTiles = 1024;   // visibility words kept in LDS (8 KiB): Sk <= 65536 in the key-padding modes
 
-template <typename Tag, int D, int MODE>
+// DROP = 1 (round 4): attention-weight dropout. Wave A draws the keep bits of its block (same hash, same (row, key quad) grouping as the
+// forward: a lane owns a row, its register groups are key quads) and publishes P with the SIGN BIT SET for a dropped weight - P is never
+// negative, so the bit is free - and wave B reads "kept" off the sign: dS = |P| o ((kept ? dP * 1/(1-p) : 0) - delta). B's dP accumulator
+// then starts at 0 (dropout scales dP before delta is subtracted).
+template <typename Tag, int D, int MODE, int DROP = 0>
 __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams bp) {
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -52,6 +56,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     const int hi = lane >> 5;
     const int role = wave >> 2;   // 0 = A, 1 = B
     const int rbw = wave & 3;     // 32-row block of this wave inside the workgroup's 128 rows
+    const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
 
     int bh, qi;
     if (VBIAS && p.batch_inner && (p.H & 7) == 0) {   // the B workgroups that read the same bias rows run together on one XCD
@@ -185,6 +190,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     const int wave_first_vis = qw0 + coff;
     const int wave_last_vis = qw0 + 31 + coff;
     const int vis = causal ? (row + coff) : 0x7fffffff;
+    const uint32_t drop_rb = DROP ? drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row) : 0u;
     // wave-uniform classification of (this wave's 32 rows) x (key tile t): identical for the A and the B wave of a row block
     auto classify = [&](int t, bool& skip, bool& need_mask, uint64_t& kp_bits) {
         const int k0 = t * KT;
@@ -275,6 +281,10 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
                             const int key = key_of(t, kb, r);
                             pv = ((key < p.Sk) && (key <= vis)) ? pv : 0.f;
                         }
+                        if (DROP) {   // registers 4g .. 4g+3 are one key quad: one state per quad, the word of key & 3 = r & 3 (CSE'd over the quad)
+                            const uint32_t hy = drop_mix(drop_rb, dsd.hi, (uint32_t)(key_of(t, kb, r & ~3) >> 2));
+                            pv = drop_keep(drop_word(hy, r & 3), p.drop_thr << 16) ? pv : -pv;
+                        }
                         x[e] = pv;
                     }
                     pf[kb][t2] = E::cvt8(x);
@@ -310,7 +320,13 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
             u32x4 pw[2];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) pw[t2] = *LDS_PTR(const u32x4, ps + (kb * 2 + t2) * 1024);
-            f32x16 pacc = seed;
+            f32x16 pacc;
+            if (DROP) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+            } else {
+                pacc = seed;
+            }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const vec8 vf = lds_read_rowfrag<E, D>(tV, kb * 32 + l31, s, hi);
@@ -323,7 +339,12 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
                 for (int e = 0; e < 8; ++e) {
                     const uint32_t word = pw[t2][e >> 1];
                     const float pv = E::to_f32((uint16_t)((e & 1) ? (word >> 16) : (word & 0xffffu)));
-                    x[e] = pv * pacc[8 * t2 + e];
+                    if (DROP) {   // sign set = dropped weight: dS = |P| ((kept ? dP / (1-p) : 0) - delta)   (stat = -delta)
+                        const float dpe = __builtin_signbit(pv) ? 0.f : pacc[8 * t2 + e] * p.drop_scale;
+                        x[e] = __builtin_fabsf(pv) * (dpe + stat);
+                    } else {
+                        x[e] = pv * pacc[8 * t2 + e];
+                    }
                 }
                 dsf[kb][t2] = E::cvt8(x);
                 // gradient of the additive bias = dS (bias modes only): registers 8*t2 .. 8*t2+7 are 8 consecutive keys

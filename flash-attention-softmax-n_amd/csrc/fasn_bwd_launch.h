@@ -38,12 +38,12 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         hipLaunchKernelGGL((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
     }
     bool dq_done = (p.skip & 2) != 0;
-    if constexpr (WS != 0 && DROP == 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
+    if constexpr (WS != 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
         const int ntiles = (p.f.Sk + KT - 1) / KT;
-        if (!dq_done && !(FASN_BWD_VARIANT & 2) && (!mode_has_keypad(MODE) || ntiles <= kDqWsMaxTiles)) {   // dQ: two cooperating waves per row block
+        if (!dq_done && !(FASN_BWD_VARIANT & 2) && (!mode_has_keypad(MODE) || ntiles <= kDqWsMaxTiles) && (!DROP || p.f.kvg == 1)) {   // dQ: two cooperating waves per row block
             constexpr int smem = 5 * KT * D * 2 + 2 * 16384 + (mode_has_vbias(MODE) ? 32768 : 0) + (mode_has_keypad(MODE) ? kDqWsMaxTiles * 8 : 0);
             p.nblk = (p.f.Sq + 127) / 128;
-            constexpr auto kern = &fasn_bwd_dq_ws_kernel<Tag, D, MODE>;
+            constexpr auto kern = &fasn_bwd_dq_ws_kernel<Tag, D, MODE, DROP>;
             ensure_smem<kern>(smem);
             hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
             dq_done = true;
@@ -61,16 +61,20 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         p.f.pair = 0;
     }
     if (p.skip & 1) return launch_rc();
-    if constexpr (WS != 0 && DROP == 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
-        if (!(FASN_BWD_VARIANT & 1)) {   // dK, dV: two cooperating waves per key block
+    if constexpr (WS != 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
+        if (!(FASN_BWD_VARIANT & 1) && (!DROP || p.f.kvg == 1)) {   // dK, dV: two cooperating waves per key block (dropout: one query head per K/V head)
             constexpr int smem = 6 * QT * D * 2 + 2 * 16384 + 6 * QT * 4 + (mode_has_vbias(MODE) ? 4 * 3 * 2048 : 0);
             p.nblk = (p.f.Sk + 127) / 128;
-            if (p.f.kvg > 1) {   // grouped-query attention: one workgroup per K/V head walks the query heads of its group
-                constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE, 1>;
-                ensure_smem<kern>(smem);
-                hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(512), smem, s, p);
-            } else {
-                constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE, 0>;
+            if constexpr (DROP == 0) {
+                if (p.f.kvg > 1) {   // grouped-query attention: one workgroup per K/V head walks the query heads of its group
+                    constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE, 1>;
+                    ensure_smem<kern>(smem);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(512), smem, s, p);
+                    return launch_rc();
+                }
+            }
+            {
+                constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE, 0, DROP>;
                 ensure_smem<kern>(smem);
                 hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
             }
@@ -98,11 +102,23 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
 template <typename Tag, int D, int QB, int KB, int OCC_Q, int OCC_K, int WS = 0>
 int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
     if (p.f.drop_thr) {   // dropout: separate instantiations (the keep-bit hash costs registers the p = 0 kernels keep)
-        if (mode == MODE_BIAS_KEYPAD) mode = p.f.keypad_fallback;   // (no dropout instantiation of its own: the dense-mask general mode)
+        // the two-wave kernels (WS: D = 128) have dropout instantiations since round 4, the vector bias + key-padding mode included;
+        // elsewhere that mode takes the dense-mask general mode of the same mask
+        if (mode == MODE_BIAS_KEYPAD) {
+            if constexpr (WS != 0) {
+                if (p.f.kvg == 1) return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, 1, 1, 1, WS>(p, s);
+            }
+            mode = p.f.keypad_fallback;
+        }
+        if (mode == MODE_GENERAL_B) {
+            if constexpr (WS != 0) {
+                if (p.f.kvg == 1) return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, 1, 1, 1, WS>(p, s);
+            }
+        }
         switch (mode) {
-            case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K, 1>(p, s);
-            case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K, 1>(p, s);
-            case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_KEYPAD, OCC_Q, OCC_K, 1>(p, s);
+            case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K, 1, WS>(p, s);
+            case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K, 1, WS>(p, s);
+            case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_KEYPAD, OCC_Q, OCC_K, 1, WS>(p, s);
             case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1, 1>(p, s);
             default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 1>(p, s);   // vector mask / bias
         }

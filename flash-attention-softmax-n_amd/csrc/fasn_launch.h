@@ -93,7 +93,12 @@ int launch_fwd_cfg(const FwdParams& p, int mode, hipStream_t s) {
 // Seeded S accumulators; the row sums stay fp32 (taken before the drop).
 template <typename Tag, int D, int QB, int OCC>
 int launch_fwd_drop(const FwdParams& p, int mode, hipStream_t s) {
-    if (mode == MODE_BIAS_KEYPAD) mode = p.keypad_fallback;   // no dropout instantiation of its own: the dense-mask general mode
+    if (mode == MODE_BIAS_KEYPAD) {
+        // vector bias + key-padding mask (ALiBi on a padded batch) with dropout: the visibility-word kernel at D = 128 (round 4), elsewhere
+        // the dense-mask general mode of the same mask
+        if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_BIAS_KEYPAD, 2, 8, 2, 1, 1>(p, s);
+        else mode = p.keypad_fallback;
+    }
     if (mode == MODE_PLAIN) {
         if constexpr (D == 128 && FASN_DROP_8WAVE) return launch_fwd_one<Tag, D, 1, MODE_PLAIN, 2, 8, 2, 1, 1>(p, s);   // 8 waves share a K/V tile, two per SIMD
         else return launch_fwd_one<Tag, D, QB, MODE_PLAIN, OCC, 4, FASN_DROP_RING, 1, 1>(p, s);
