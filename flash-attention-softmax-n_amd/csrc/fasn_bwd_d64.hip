@@ -14,11 +14,11 @@ int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (p.dqacc != nullptr)   // developer library: fasn_api.hip sets the accumulator only where the one-pass backward applies
         return launch_bwd_fused_d64(p, l, s);
 #endif
-    // plain / causal without dropout or grouped K/V: the software-pipelined kernels of fasn_bwd_pipe.h
+    // plain / causal without grouped K/V: the software-pipelined kernels of fasn_bwd_pipe.h
     // (developer library: bwd_variant bit 6 / bit 7 = the round-3 dK/dV / dQ kernel instead, for same-box A/B)
     BwdParams q = p;
     q.skip = 0;
-    const bool pipe_ok = (l.mode == MODE_PLAIN || l.mode == MODE_CAUSAL) && p.f.drop_thr == 0 && p.f.kvg == 1;
+    const bool pipe_ok = (l.mode == MODE_PLAIN || l.mode == MODE_CAUSAL) && p.f.kvg == 1;   // (with or without dropout)
     if (pipe_ok && !(FASN_BWD_VARIANT & 64)) q.skip |= 1;
     if (pipe_ok && !(FASN_BWD_VARIANT & 128)) q.skip |= 2;
     int rc = l.dtype == 1 ? launch_bwd_mode<bf16_tag, 64, 1, 1, 2, 2>(q, l.mode, s) : launch_bwd_mode<f16_tag, 64, 1, 1, 2, 2>(q, l.mode, s);

@@ -24,7 +24,10 @@ constexpr int PNB = 3;    // Q / dO tile buffers
 constexpr int pipe_dkdv_smem_bytes() { return 2 * PNB * PQT * 64 * 2 + 2 * PNB * PQT * 4; }
 
 // dK, dV: workgroup = 4 waves x 32 keys; a lane owns a key column (S, dP, dS are [row][key] accumulator tiles).
-template <typename Tag, int MODE>
+// DROP = 1: attention-weight dropout - the keep bits of a block are drawn in its element pass (the four lanes of a key quad compute one
+// (row, key quad) hash state each and exchange them with DPP quad_perm moves, see fasn_bwd_dkdv_ws.h); dP then starts at 0 and -delta
+// waits in 16 registers (dropout scales dP before delta is subtracted), dV takes the kept weights and its 1/(1-p) at the end.
+template <typename Tag, int MODE, int DROP = 0>
 __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdParams bp) {
     static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "pipelined dK/dV: plain and causal");
     using E = ET<Tag>;
@@ -45,6 +48,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int hi = lane >> 5;
+    const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
 
     int bh, kblk0;
     block_to_work((int)blockIdx.x, p.B * p.H, (causal && p.pair) ? (bp.nblk + 1) / 2 : bp.nblk, bh, kblk0);
@@ -159,6 +163,8 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
     vec8 qa[KS], da[KS];       // row fragments of the block whose S MFMAs come next
     vec8 dot[2][DB], qt[2][DB];   // transposed fragments of the block whose G MFMAs come next
     vec8 pk[2], dsk[2];        // 16-bit P, dS of that block
+    f32x16 xr;                 // DROP: -delta of the rows of the block whose element pass comes next
+    const DropLane dlane = drop_lane(key & 3);
 
     // The phases are cut into sched_barrier-delimited pieces so that the register allocator can time-share one 32-register block
     // between the row fragments (live from phase b of block j-1 to the S MFMAs of block j) and the transposed fragments (live from
@@ -184,7 +190,10 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
         for (int g = 0; g < 4; ++g) {
             const f32x4 c = *LDS_PTR(const f32x4, tX + qb * 32 + 8 * g + 4 * hi);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pp[4 * g + e] = c[e];
+            for (int e = 0; e < 4; ++e) {
+                if (DROP) xr[4 * g + e] = c[e];
+                else pp[4 * g + e] = c[e];
+            }
         }
     };
     auto mfma_S1 = [&](f32x16& s) __attribute__((always_inline)) {
@@ -192,8 +201,15 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
         for (int ks = 0; ks < KS; ++ks) s = E::mfma(qa[ks], kf[ks], s);
     };
     auto mfma_S2 = [&](f32x16& pp) __attribute__((always_inline)) {
+        if (DROP) {   // dP starts at 0
+            const f32x16 zero = {};
+            pp = E::mfma(da[0], vf[0], zero);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) pp = E::mfma(da[ks], vf[ks], pp);
+            for (int ks = 1; ks < KS; ++ks) pp = E::mfma(da[ks], vf[ks], pp);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) pp = E::mfma(da[ks], vf[ks], pp);
+        }
     };
     auto load_tr = [&](int bo, int qb, int t2) __attribute__((always_inline)) {
         const char* tQ = ldsQ + bo;
@@ -211,13 +227,28 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
             dkacc[d] = E::mfma(qt[t2][d], dsk[t2], dkacc[d]);
         }
     };
-    auto elem_half = [&](f32x16& s, f32x16& pp, int half) __attribute__((always_inline)) {
+    auto elem_half = [&](f32x16& s, f32x16& pp, int half, int r0) __attribute__((always_inline)) {   // (r0: first row of the block)
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int r = 8 * half + rr;
             const float pv = fast_exp2(s[r]);
-            s[r] = pv;
-            pp[r] = pv * pp[r];
+            if (DROP) {
+                const int g = r >> 2;
+                const uint32_t own = drop_mix(drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)(r0 + 8 * g + 4 * hi + (lane & 3))), dsd.hi, (uint32_t)(key >> 2));   // (one per g: CSE)
+                uint32_t hy;
+                switch (r & 3) {   // quad_perm broadcast of lane (quad base + (r & 3)): the state of THIS register's row
+                    case 0: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0x00, 0xf, 0xf, false); break;
+                    case 1: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0x55, 0xf, 0xf, false); break;
+                    case 2: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xAA, 0xf, 0xf, false); break;
+                    default: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xFF, 0xf, 0xf, false); break;
+                }
+                const bool keep = drop_keep(drop_word(hy, dlane), p.drop_thr << 16);
+                s[r] = keep ? pv : 0.f;                                             // what dV multiplies (its 1/(1-p) at the end)
+                pp[r] = pv * ((keep ? pp[r] * p.drop_scale : 0.f) + xr[r]);          // dS = P o (dropped dP - delta)
+            } else {
+                s[r] = pv;
+                pp[r] = pv * pp[r];
+            }
         }
     };
     auto pack = [&](const f32x16& s, const f32x16& pp) __attribute__((always_inline)) {
@@ -270,11 +301,11 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
     auto phase_b = [&](auto HAVE_PREV, f32x16& s, f32x16& pp, int nbo, int nqb, int nr0, f32x16& ns, f32x16& npp) __attribute__((always_inline)) {
         constexpr bool hp = decltype(HAVE_PREV)::value;
         if (hp) mfma_G(0);
-        elem_half(s, pp, 0);
+        elem_half(s, pp, 0, nr0 - 32);   // (the block in its element pass is the one before the block being requested)
         FASN_SB();
         load_rf_q(nbo, nqb, ns);
         if (hp) mfma_G(1);
-        elem_half(s, pp, 1);
+        elem_half(s, pp, 1, nr0 - 32);
         pin(s), pin(pp);
         FASN_SB();
         load_rf_d(nbo, nqb, npp);
@@ -336,7 +367,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     x[e] = dkacc[d][4 * g + e] * bp.scale;
-                    y[e] = dvacc[d][4 * g + e];
+                    y[e] = DROP ? dvacc[d][4 * g + e] * p.drop_scale : dvacc[d][4 * g + e];
                 }
                 typename E::vec4 xk = E::cvt4(x), yv = E::cvt4(y);
                 u32x2 ra, rb;
@@ -701,7 +732,9 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dkdv_pipe2_kernel(const BwdPa
 // diagonal and the ragged last key tile zero hidden P in a small wave-uniform branch between B and A.
 constexpr int pipe_dq_smem_bytes() { return 2 * PNB * KT * 64 * 2; }
 
-template <typename Tag, int MODE>
+// DROP = 1: the keep bits are drawn with the exponentials (a lane owns a row: one hash state per key quad, as in the forward) and kept
+// as the SIGN of P until the products; dP starts at 0: dS = |P| o ((kept ? dP / (1-p) : 0) - delta).
+template <typename Tag, int MODE, int DROP = 0>
 __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParams bp) {
     static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "pipelined dQ: plain and causal");
     using E = ET<Tag>;
@@ -720,6 +753,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int hi = lane >> 5;
+    const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
 
     int bh, qi;
     block_to_work((int)blockIdx.x, p.B * p.H, (causal && p.pair) ? (bp.nblk + 1) / 2 : bp.nblk, bh, qi);
@@ -835,8 +869,11 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
 #pragma unroll
         for (int ks = 1; ks < KS; ++ks) s = E::mfma(kf[ks], qf[ks], s);
     };
+    const float ndlt = -dlt;
+    const uint32_t drop_rb = DROP ? drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row) : 0u;
     auto mfma_P = [&]() __attribute__((always_inline)) {
-        pa = E::mfma(vf[0], dof[0], dseed);
+        const f32x16 zero = {};
+        pa = E::mfma(vf[0], dof[0], DROP ? zero : dseed);
 #pragma unroll
         for (int ks = 1; ks < KS; ++ks) pa = E::mfma(vf[ks], dof[ks], pa);
     };
@@ -846,16 +883,31 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
 #pragma unroll
             for (int d = 0; d < DB; ++d) dqacc[d] = E::mfma(ktf[t2][d], dsf[t2], dqacc[d]);
     };
-    auto exps = [&](f32x16& s) __attribute__((always_inline)) {
+    auto exps = [&](f32x16& s, int k0) __attribute__((always_inline)) {   // (k0: first key of the block)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]);
+        for (int r = 0; r < 16; ++r) {
+            float pv = fast_exp2(s[r]);
+            if (DROP) {   // registers 4g .. 4g+3 are one key quad (keys k0 + 8g + 4hi + 0..3): one state per quad, the word of key & 3 = r & 3
+                const uint32_t hy = drop_mix(drop_rb, dsd.hi, (uint32_t)((k0 + 8 * (r >> 2) + 4 * hi) >> 2));
+                pv = drop_keep(drop_word(hy, r & 3), p.drop_thr << 16) ? pv : -pv;
+            }
+            s[r] = pv;
+        }
     };
     auto mulpack = [&](const f32x16& s) __attribute__((always_inline)) {   // dS^T = P^T o dP'^T, 16 bit
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             f32x8 y;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = s[8 * t2 + e] * pa[8 * t2 + e];
+            for (int e = 0; e < 8; ++e) {
+                if (DROP) {
+                    const float pv = s[8 * t2 + e];
+                    const float dpe = __builtin_signbit(pv) ? 0.f : pa[8 * t2 + e] * p.drop_scale;
+                    y[e] = __builtin_fabsf(pv) * (dpe + ndlt);
+                } else {
+                    y[e] = s[8 * t2 + e] * pa[8 * t2 + e];
+                }
+            }
             dsf[t2] = E::cvt8(y);
         }
     };
@@ -889,7 +941,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
     auto phase_B = [&](auto HAVE_PREV, f32x16& s, int k0, int nbo, int nkb) __attribute__((always_inline)) {
         constexpr bool hp = decltype(HAVE_PREV)::value;
         mfma_P();
-        exps(s);
+        exps(s, k0);
         if (hp) mfma_G();
         pin(s);
         FASN_SB();

@@ -3,35 +3,39 @@
 #include "fasn_bwd_pipe.h"
 namespace fasn {
 
-template <typename Tag, int MODE>
+template <typename Tag, int MODE, int DROP>
 static int launch_dkdv_pipe(BwdParams p, hipStream_t s) {
     constexpr int BN = 128;
     constexpr int smem = pipe_dkdv_smem_bytes();
     const int nbh = p.f.B * p.f.H;
     p.nblk = (p.f.Sk + BN - 1) / BN;
-    constexpr auto kern = &fasn_bwd_dkdv_pipe_kernel<Tag, MODE>;
+    constexpr auto kern = &fasn_bwd_dkdv_pipe_kernel<Tag, MODE, DROP>;
     ensure_smem<kern>(smem);
     p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * 2)) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
     return launch_rc();
 }
 
-template <typename Tag, int MODE>
+template <typename Tag, int MODE, int DROP>
 static int launch_dq_pipe(BwdParams p, hipStream_t s) {
     constexpr int BM = 128;
     constexpr int smem = pipe_dq_smem_bytes();
     const int nbh = p.f.B * p.f.H;
     p.nblk = (p.f.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_bwd_dq_pipe_kernel<Tag, MODE>;
+    constexpr auto kern = &fasn_bwd_dq_pipe_kernel<Tag, MODE, DROP>;
     ensure_smem<kern>(smem);
     p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * 2)) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
     return launch_rc();
 }
 
+template <typename Tag, int DROP>
+static int dq_pipe_mode(const BwdParams& p, int mode, hipStream_t s) {
+    return mode == MODE_CAUSAL ? launch_dq_pipe<Tag, MODE_CAUSAL, DROP>(p, s) : launch_dq_pipe<Tag, MODE_PLAIN, DROP>(p, s);
+}
 int launch_bwd_dq_pipe_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
-    if (l.mode == MODE_CAUSAL) return l.dtype == 1 ? launch_dq_pipe<bf16_tag, MODE_CAUSAL>(p, s) : launch_dq_pipe<f16_tag, MODE_CAUSAL>(p, s);
-    return l.dtype == 1 ? launch_dq_pipe<bf16_tag, MODE_PLAIN>(p, s) : launch_dq_pipe<f16_tag, MODE_PLAIN>(p, s);
+    if (p.f.drop_thr) return l.dtype == 1 ? dq_pipe_mode<bf16_tag, 1>(p, l.mode, s) : dq_pipe_mode<f16_tag, 1>(p, l.mode, s);
+    return l.dtype == 1 ? dq_pipe_mode<bf16_tag, 0>(p, l.mode, s) : dq_pipe_mode<f16_tag, 0>(p, l.mode, s);
 }
 
 #ifdef FASN_DEV_VARIANTS   // one wave per SIMD, 64 keys per wave: measured slower (1241 against 1031 us at M0), developer library only
@@ -53,8 +57,12 @@ int launch_bwd_dkdv_pipe2_d64(const BwdParams& p, const FwdLaunch& l, hipStream_
 }
 #endif
 
+template <typename Tag, int DROP>
+static int dkdv_pipe_mode(const BwdParams& p, int mode, hipStream_t s) {
+    return mode == MODE_CAUSAL ? launch_dkdv_pipe<Tag, MODE_CAUSAL, DROP>(p, s) : launch_dkdv_pipe<Tag, MODE_PLAIN, DROP>(p, s);
+}
 int launch_bwd_dkdv_pipe_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
-    if (l.mode == MODE_CAUSAL) return l.dtype == 1 ? launch_dkdv_pipe<bf16_tag, MODE_CAUSAL>(p, s) : launch_dkdv_pipe<f16_tag, MODE_CAUSAL>(p, s);
-    return l.dtype == 1 ? launch_dkdv_pipe<bf16_tag, MODE_PLAIN>(p, s) : launch_dkdv_pipe<f16_tag, MODE_PLAIN>(p, s);
+    if (p.f.drop_thr) return l.dtype == 1 ? dkdv_pipe_mode<bf16_tag, 1>(p, l.mode, s) : dkdv_pipe_mode<f16_tag, 1>(p, l.mode, s);
+    return l.dtype == 1 ? dkdv_pipe_mode<bf16_tag, 0>(p, l.mode, s) : dkdv_pipe_mode<f16_tag, 0>(p, l.mode, s);
 }
 }  // namespace fasn
