@@ -23,7 +23,7 @@ BASELINE_KERNELS = {
     "c3 f16 D=64 causal forward": r"fasn_fwd_kernelINS_7f16_tagELi64ELi1ELi1E",
     "c5 bf16 D=64 causal forward": r"fasn_fwd_kernelINS_8bf16_tagELi64ELi1ELi1E",
     "c4 bf16 D=128 ALiBi + key padding forward": r"fasn_fwd_kernelINS_8bf16_tagELi128ELi1ELi7E",
-    "m0 / c2 / c3 / c5 backward (delta, pipelined dQ, pipelined dK/dV)": r"fasn_bwd_delta_kernelINS_(8bf16|7f16)_tagELi64E|fasn_bwd_dq_pipe_kernelINS_\\w+_tagELi[01]ELi0E|fasn_bwd_dkdv_pipe_kernelINS_\\w+_tagELi[01]ELi0E",
+    "m0 / c2 / c3 / c5 backward (delta, pipelined dQ, pipelined dK/dV)": r"fasn_bwd_delta_kernelINS_(8bf16|7f16)_tagELi64E|fasn_bwd_dq_pipe_kernelINS_\w+_tagELi[01]ELi0E|fasn_bwd_dkdv_pipe_kernelINS_\w+_tagELi[01]ELi0E",
     "c4 backward (delta, two-wave dQ, two-wave dK/dV)": r"fasn_bwd_delta_kernelINS_8bf16_tagELi128E|fasn_bwd_dq_ws_kernelINS_8bf16_tagELi128ELi7ELi0E|fasn_bwd_dkdv_ws_kernelINS_8bf16_tagELi128ELi7ELi0ELi0E",
 }
 
