@@ -5,14 +5,31 @@
 // register-staged into two LDS buffers. Mask / bias: the vector kernel serves every combination (an absent operand is a
 // zero-range descriptor / an all-ones word), key padding rides the plain kernel, everything else the element-load kernel.
 #include "fasn_launch.h"
+#include "fasn_fwd_ws256.h"
 namespace fasn {
+// plain / causal: the two-wave kernel (fasn_fwd_ws256.h, round 4): 128-row workgroups of 8 waves, no score computed twice
+template <typename Tag, int MODE>
+static int launch_ws256(FwdParams p, hipStream_t s) {
+    constexpr int smem = ws256_smem_bytes();
+    p.nqblk = (p.Sq + 127) / 128;
+    constexpr auto kern = &fasn_fwd_ws256_kernel<Tag, MODE>;
+    ensure_smem<kern>(smem);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(512), smem, s, p);
+    return launch_rc();
+}
 template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (p.drop_thr) return launch_fwd_one<Tag, 256, 1, MODE_GENERAL_SLOW, 1, 4, 0, 0, 1, 2>(p, s);   // dropout: the element-load kernel
     const int mode = l.mode == MODE_BIAS_KEYPAD ? p.keypad_fallback : l.mode;   // bias + key padding: the dense-mask view of the same mask
+#ifdef FASN_DEV_VARIANTS
+    if (l.variant == 1) {   // A/B: the round-3 feature-half kernels
+        if (mode == MODE_PLAIN) return launch_fwd_one<Tag, 256, 1, MODE_PLAIN, 1, 4, 0, 2, 0, 2>(p, s);
+        if (mode == MODE_CAUSAL) return launch_fwd_one<Tag, 256, 1, MODE_CAUSAL, 1, 4, 0, 2, 0, 2>(p, s);
+    }
+#endif
     switch (mode) {
-        case MODE_PLAIN: return launch_fwd_one<Tag, 256, 1, MODE_PLAIN, 1, 4, 0, 2, 0, 2>(p, s);
-        case MODE_CAUSAL: return launch_fwd_one<Tag, 256, 1, MODE_CAUSAL, 1, 4, 0, 2, 0, 2>(p, s);
+        case MODE_PLAIN: return launch_ws256<Tag, MODE_PLAIN>(p, s);
+        case MODE_CAUSAL: return launch_ws256<Tag, MODE_CAUSAL>(p, s);
         case MODE_KEYPAD: return launch_fwd_one<Tag, 256, 1, MODE_KEYPAD, 1, 4, 0, 2, 0, 2>(p, s);
         case MODE_GENERAL: case MODE_GENERAL_B: case MODE_GENERAL_M: return launch_fwd_one<Tag, 256, 1, MODE_GENERAL, 1, 4, 0, 2, 0, 2>(p, s);
         default: return launch_fwd_one<Tag, 256, 1, MODE_GENERAL_SLOW, 1, 4, 0, 0, 0, 2>(p, s);

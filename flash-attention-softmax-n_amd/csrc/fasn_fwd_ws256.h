@@ -1,0 +1,276 @@
+// fasn_fwd_ws256.h — forward at head dim 256 with the two GEMMs of a score block split over TWO cooperating waves of one SIMD
+// (the forward counterpart of fasn_bwd_dq_ws.h; reference math: core/functional.py:15-29,32-93, FA-2 recurrence with the "+n" sink).
+//
+// Round 3 served D = 256 with one wave per SIMD and "feature halves": Q^T fragments (64 registers) plus a full O^T accumulator (128)
+// do not fit next to the score tile, so two workgroups shared a row block, each computed QK^T in full and owned half of the output
+// features - 3 GEMM-equivalents for 2, one wave per SIMD, 0.15 of the MFMA peak. Here a workgroup has 8 waves for 128 query rows; waves
+// w and w + 4 share a SIMD and the same 32 rows (a lane owns one query row, as everywhere in the forward):
+//
+//   wave A (w < 4):  S^T = K Q'^T  ->  online softmax_n (running max m, sum l)  ->  P^T (16 bit) and the rescale factor to LDS
+//   wave B (w >= 4): reads P^T / alpha of the previous key block  ->  O^T = alpha O^T + V^T P^T
+//
+// A holds Q' (64 registers) and the statistics, B the O^T accumulator (128): both fit 256 registers, two waves per SIMD, 16 MFMAs
+// each per 32-key block, no score computed twice. B runs one key block behind A: the P^T of block u is published by the barrier
+// that ends iteration u. K / V arrive by LDS-DMA in units of 32 keys (16 KiB images [32][256], swizzled like every tile), K and V in rings
+// of four, both requested two blocks ahead of their first reader (vmcnt counts in order: a deeper K ring behind a shallow V ring would
+// be drained by the wait for V anyway); one barrier per block. Plain and causal launches (the key-padding / bias /
+// dropout modes stay on the feature-half kernels).
+#pragma once
+#include "fasn_fwd_kernel.h"
+
+namespace fasn {
+
+constexpr int W256_NK = 4, W256_NV = 4;           // K / V ring slots
+constexpr int W256_UNIT = 32 * 256 * 2;           // one 32-key image
+constexpr int ws256_smem_bytes() { return (W256_NK + W256_NV) * W256_UNIT + 2 * 4 * 2048 + 2 * 4 * 256; }
+
+template <typename Tag, int MODE>
+__global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams p) {
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "two-wave D = 256 forward: plain and causal");
+    using E = ET<Tag>;
+    using vec8 = typename E::vec8;
+    constexpr int D = 256, KS = 16, DB = 8, BM = 128, KU = 32;
+    constexpr bool causal = MODE == MODE_CAUSAL;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsK = smem;                                        // [W256_NK][UNIT]
+    char* const ldsV = smem + W256_NK * W256_UNIT;                  // [W256_NV][UNIT]
+    char* const ldsP = smem + (W256_NK + W256_NV) * W256_UNIT;      // [2][4 row blocks][2 KiB]
+    float* const ldsA = reinterpret_cast<float*>(ldsP + 2 * 4 * 2048);   // [2][4][64] rescale factor of the lane's row
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+    const int role = wave >> 2;   // 0 = A, 1 = B
+    const int rbw = wave & 3;
+
+    int bh, qi;
+    block_to_work((int)blockIdx.x, p.B * p.H, p.nqblk, bh, qi);
+    const int qblk = causal ? (p.nqblk - 1 - qi) : qi;   // heaviest blocks first
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qblk * BM;
+    const int qw0 = q0 + rbw * 32;
+    const int row = qw0 + l31;
+    const bool row_ok = row < p.Sq;
+    const int coff = p.Sk - p.Sq;
+    const int vis = causal ? row + coff : 0x7fffffff;
+
+    const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2;
+    const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2;
+
+    int nu = (p.Sk + KU - 1) / KU;   // key blocks this workgroup walks
+    if (causal) {
+        const int kmax = min(q0 + BM, p.Sq) - 1 + coff;
+        nu = min(nu, kmax < 0 ? 0 : kmax / KU + 1);
+    }
+
+    // ---- K / V units straight to LDS: thread `tid` owns 16-byte slots tid and tid + 512 of an image
+    unsigned voffK[2], voffV[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ci = tid + i * 512;
+        const int r = ci >> 5, ch = (ci & 31) ^ swz_f<D>(r);
+        voffK[i] = (unsigned)(r * (int)p.ks[2] * 2 + ch * 16);
+        voffV[i] = (unsigned)(r * (int)p.vs[2] * 2 + ch * 16);
+    }
+    const u32x4 krw = make_rsrc_words(kbase, p.kbytes), vrw = make_rsrc_words(vbase, p.vbytes);
+    const uint32_t ldsK_w = lds_addr(ldsK) + wave * 1024, ldsV_w = lds_addr(ldsV) + wave * 1024;
+    auto k_dma = [&](int u, int slot) {   // (units past the end of K read back as zeros; 2 requests)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16(krw, __builtin_amdgcn_readfirstlane(ldsK_w + slot * W256_UNIT + i * 8192), voffK[i], u * KU * (int)p.ks[2] * 2);
+    };
+    auto v_dma = [&](int u, int slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16(vrw, __builtin_amdgcn_readfirstlane(ldsV_w + slot * W256_UNIT + i * 8192), voffV[i], u * KU * (int)p.vs[2] * 2);
+    };
+
+    // ---- prologue: the first K / V units (iteration u requests K unit u + 3 and V unit u + 2; before the loop: K 0..2, V 0..1)
+#pragma unroll
+    for (int u = 0; u < W256_NK - 1; ++u) k_dma(u, u);
+    v_dma(0, 0);
+    v_dma(1, 1);
+    // softmax_n state of the lane's row: the sink column (logit 0, weight n) is the start value; each half-wave sums its own 16 keys
+    // per block and the halves are merged at the end (the maximum is shared every block, so both halves scale alike)
+    float m_run = p.n > 0.f ? 0.f : -INFINITY;
+    float l_run = (p.n > 0.f && hi == 0) ? p.n : 0.f;
+    const int wave_first_vis = qw0 + coff, wave_last_vis = qw0 + 31 + coff;
+    // wave-uniform classification of (this wave's 32 rows) x (key block u): identical for the A and the B wave of a row block
+    auto classify = [&](int u, bool& skip, bool& need_mask) {
+        const int k0 = u * KU;
+        skip = qw0 >= p.Sq;
+        need_mask = k0 + KU > p.Sk;
+        if (causal) {
+            skip = skip || k0 > wave_last_vis;
+            need_mask = need_mask || (k0 + KU - 1) > wave_first_vis;
+        }
+    };
+    char* const pslot = ldsP + rbw * 2048 + lane * 16;      // + parity * 8192 (+ 1024 for the second half of the block)
+    float* const aslot = ldsA + rbw * 64 + lane;            // + parity * 256
+
+    // ---- wave A: key block u
+    auto block_a = [&](const int u, const int kslot, const vec8 (&qf)[KS]) {
+        bool skip, need_mask;
+        classify(u, skip, need_mask);
+        char* ps = pslot + (u & 1) * 8192;
+        if (skip) {   // nothing visible to these rows: B is told to leave its accumulator alone and gets zero weights
+            *LDS_PTR(u32x4, ps) = u32x4{0u, 0u, 0u, 0u};
+            *LDS_PTR(u32x4, ps + 1024) = u32x4{0u, 0u, 0u, 0u};
+            aslot[(u & 1) * 256] = 1.0f;
+            return;
+        }
+        const char* tK = ldsK + kslot * W256_UNIT;
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const vec8 kf = lds_read_rowfrag<E, D>(tK, l31, s, hi);
+            sacc = E::mfma(kf, qf[s], sacc);
+        }
+        if (need_mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = u * KU + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                sacc[r] = (key < p.Sk && key <= vis) ? sacc[r] : -INFINITY;
+            }
+        }
+        float tmax = sacc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[r]);
+        tmax = max_across_halves(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;   // (a row that has seen no key yet: every weight exp2(-inf) = 0)
+        const float alpha = fast_exp2(m_run - m_use);           // m_run = -inf: 0, and l / O are 0 there anyway
+        m_run = m_new;
+        float rs = 0.f;
+        vec8 pfr[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            f32x8 x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x[e] = fast_exp2(sacc[8 * t2 + e] - m_use);
+                rs += x[e];
+            }
+            pfr[t2] = E::cvt8(x);
+        }
+        l_run = l_run * alpha + rs;
+        u32x4 w0, w1;
+        __builtin_memcpy(&w0, &pfr[0], 16);
+        __builtin_memcpy(&w1, &pfr[1], 16);
+        *LDS_PTR(u32x4, ps) = w0;
+        *LDS_PTR(u32x4, ps + 1024) = w1;
+        aslot[(u & 1) * 256] = alpha;
+    };
+    // ---- wave B: key block u (the one wave A finished in the previous iteration)
+    auto block_b = [&](const int u, const int vslot, f32x16 (&oacc)[DB]) {
+        const char* ps = pslot + (u & 1) * 8192;
+        const u32x4 w0 = *LDS_PTR(const u32x4, ps), w1 = *LDS_PTR(const u32x4, ps + 1024);
+        const float alpha = aslot[(u & 1) * 256];
+        bool skip, need_mask;
+        classify(u, skip, need_mask);
+        if (skip) return;
+        if (__any(alpha != 1.0f)) {   // some row's running maximum moved (every row in the first blocks, rarely later)
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
+        vec8 pfr[2];
+        __builtin_memcpy(&pfr[0], &w0, 16);
+        __builtin_memcpy(&pfr[1], &w1, 16);
+        const char* tV = ldsV + vslot * W256_UNIT;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const vec8 vtf = lds_read_trfrag<E, D>(tV, 16 * t2, d, lane);
+                oacc[d] = E::mfma(vtf, pfr[t2], oacc[d]);
+            }
+    };
+
+    // iteration u: A works on K unit u, B on V unit u - 1; K unit u + 3 and V unit u + 2 are requested (their slots were released by
+    // the barrier that ended iteration u - 1). K unit u + 1 and V unit u - needed in iteration u + 1 - were requested in iteration
+    // u - 2, so the wait that ends an iteration leaves the requests of this iteration and the previous one in flight: 2 x (2 + 2) per wave.
+    // Each role runs its own copy of the loop (same trip count, same barriers): Q' lives in A's branch only, O^T in B's.
+    auto requests = [&](int u) {
+        k_dma(u + 3 < nu ? u + 3 : nu + 8, (u + 3) & 3);   // (past the end: zero fill, keeps the request counts uniform)
+        v_dma(u + 2 < nu ? u + 2 : nu + 8, (u + 2) & 3);
+    };
+    auto close = [&]() {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();
+    };
+    if (role == 0) {
+        vec8 qf[KS];
+        {
+            const char* rq = p.q + (b * p.qs[0] + h * p.qs[1] + (int64_t)row * p.qs[2]) * 2 + hi * 16;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                u32x4 a = {0u, 0u, 0u, 0u};
+                if (row_ok) a = gload16(rq + s * 32);
+                __builtin_memcpy(&qf[s], &a, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {   // Q' = Q * scale*log2e, rounded to the operand type (as core/flash_attn.py:81-83 does with its pre-scaled q)
+            retire_loads(qf[s]);
+            uint16_t hq[8];
+            __builtin_memcpy(hq, &qf[s], 16);
+            f32x8 f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hq[e]) * p.c;
+            qf[s] = E::cvt8(f);
+        }
+        for (int u = 0; u <= nu; ++u) {
+            requests(u);
+            if (u < nu) block_a(u, u & 3, qf);
+            close();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float l_tot = sum_across_halves(l_run);
+        aslot[0] = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (row_ok && p.lse != nullptr && hi == 0) {
+            const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+            p.lse[(int64_t)bh * p.Sq + row] = l_tot > 0.f ? (m_use + __builtin_log2f(l_tot)) * kLn2 : -INFINITY;
+        }
+        __syncthreads();
+    } else {
+        f32x16 oacc[DB];
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int u = 0; u <= nu; ++u) {
+            requests(u);
+            if (u > 0) block_b(u - 1, (u - 1) & 3, oacc);
+            close();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // 1 / l of every row is published
+        if (row_ok) {
+            const float inv = aslot[0];
+            char* rp = p.o + (b * p.os[0] + h * p.os[1] + (int64_t)row * p.os[2]) * 2;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = oacc[d][4 * g + e] * inv;
+                    typename E::vec4 y = E::cvt4(x);
+                    u32x2 raw;
+                    __builtin_memcpy(&raw, &y, 8);
+                    gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
+                }
+        }
+    }
+}
+
+}  // namespace fasn
