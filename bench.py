@@ -45,10 +45,9 @@ PEAK_TFLOPS_F32 = 157.3   # fp32-input MFMA (v_mfma_f32_32x32x2_f32) = the fp32 
 # GEMM-equivalents (one = 2*B*H*Sq*Sk*D flops): forward 2 (QK^T, PV); backward 5 in the textbook algorithm (S, dP, dV, dK, dQ),
 # 7 executed by the deterministic two-kernel split (S and dP are recomputed by both the dQ and the dK/dV kernel)
 GEMMS = {"fwd": (2, 2), "bwd": (5, 7), "fwdbwd": (7, 9)}
-# D = 256: the forward is the two-wave kernel of fasn_fwd_ws256.h since round 4 (2 for 2; the round-3 feature halves executed 3). In the
-# backward two workgroups per key block still each own half of the output features and both compute the scores: the dK/dV kernel
-# executes S and dP twice (6 for 4; + dQ's 3 = 9 for 5)
-GEMMS256 = {"fwd": (2, 2), "bwd": (5, 9), "fwdbwd": (7, 11)}
+# D = 256 (round 4): the two-wave kernels of fasn_fwd_ws256.h / fasn_bwd_ws256.h execute what D <= 128 executes (round 3's feature
+# halves: 3 for 2 forward, 9 for 5 backward)
+GEMMS256 = {"fwd": (2, 2), "bwd": (5, 7), "fwdbwd": (7, 9)}
 
 
 def fwd_flops(B, H, S, D, causal):

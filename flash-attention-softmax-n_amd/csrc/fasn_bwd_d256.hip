@@ -3,11 +3,42 @@
 // the dK/dV kernel runs as two workgroups per key block that each own half of the features, DH = 2).
 // Key padding rides the plain kernels; dense masks, bias and dropout take the element-load kernels.
 #include "fasn_bwd_launch.h"
+#include "fasn_bwd_ws256.h"
 namespace fasn {
+// plain / causal without dropout or grouped K/V: the two-wave kernels of fasn_bwd_ws256.h (round 4): delta, dQ, dK/dV
+template <typename Tag, int MODE>
+static int launch_ws256(BwdParams p, hipStream_t s) {
+    constexpr int D = 256;
+    const int nbh = p.f.B * p.f.H;
+    {
+        constexpr int RPB = 256 / (D / 8);
+        const int64_t rows = (int64_t)nbh * p.f.Sq;
+        hipLaunchKernelGGL((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
+    }
+    {
+        constexpr int smem = bwd_dq_ws256_smem_bytes();
+        p.nblk = (p.f.Sq + 127) / 128;
+        constexpr auto kern = &fasn_bwd_dq_ws256_kernel<Tag, MODE>;
+        ensure_smem<kern>(smem);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+    }
+    {
+        constexpr int smem = bwd_ws256_smem_bytes();
+        p.nblk = (p.f.Sk + 127) / 128;
+        constexpr auto kern = &fasn_bwd_dkdv_ws256_kernel<Tag, MODE>;
+        ensure_smem<kern>(smem);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+    }
+    return launch_rc();
+}
 template <typename Tag>
 static int go(const BwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_BIAS_KEYPAD) mode = p.f.keypad_fallback;   // bias + key padding: the dense-mask view of the same mask
     if (p.f.drop_thr) return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL_SLOW, 1, 1, 1, 0, 2>(p, s);
+    if (p.f.kvg == 1 && !(FASN_BWD_VARIANT & 1)) {   // (developer library: bwd_variant bit 0 = the round-3 feature-half kernels, for A/B)
+        if (mode == MODE_PLAIN) return launch_ws256<Tag, MODE_PLAIN>(p, s);
+        if (mode == MODE_CAUSAL) return launch_ws256<Tag, MODE_CAUSAL>(p, s);
+    }
     switch (mode) {
         case MODE_CAUSAL: return launch_bwd_one<Tag, 256, 1, 1, MODE_CAUSAL, 1, 1, 0, 0, 2>(p, s);
         case MODE_PLAIN:   // the key-padding instantiation without a mask (every key visible): the plain one spills at this head dim

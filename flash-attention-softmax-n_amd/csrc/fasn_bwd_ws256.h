@@ -1,0 +1,527 @@
+// fasn_bwd_ws256.h — backward at head dim 256 with the GEMMs of a score block split over TWO cooperating waves of one SIMD
+// (the D = 256 counterparts of fasn_bwd_dkdv_ws.h / fasn_bwd_dq_ws.h, built like fasn_fwd_ws256.h: 32-row / 32-key units, LDS-DMA
+// rings, one barrier per unit). Same mathematics as everywhere (fasn_bwd_kernel.h; reference: flash_attn_triton.py:146-235 with an LSE
+// that carries n). Round 3 ran D = 256 on the one-wave kernels with "feature halves": two workgroups per key block each computed S
+// and dP in full (9 GEMM-equivalents executed for the algorithm's 5) and spilled 87 - 156 registers.
+//
+//   dK/dV, a lane owns a key:   wave A:  S = Q K'^T (seeded with -LSE) -> P = exp2(S) -> P (16 bit) to LDS -> dV^T += dO^T P
+//                               wave B:  dP' = dO V^T (seeded with -delta), reads P    -> dS = P o dP'      -> dK^T += Q^T dS
+//   dQ, a lane owns a row:      wave A:  S^T = K Q'^T (seeded with -LSE) -> P^T = exp2(S^T) -> P^T (16 bit) to LDS
+//                               wave B:  dP'^T = V dO^T (seeded with -delta), reads P^T -> dS^T = P^T o dP'^T -> dQ^T += K^T dS^T
+//
+// Every wave holds ONE output accumulator (128 registers) and ONE operand fragment set (64): 7 GEMM-equivalents executed, no spills.
+// B runs one unit behind A; plain and causal launches without dropout, one query head per K/V head (the rest keeps the one-wave kernels).
+#pragma once
+#include "fasn_bwd_kernel.h"
+
+namespace fasn {
+
+constexpr int B256_UNIT = 32 * 256 * 2;   // one 32-row image [32][256] 16 bit
+constexpr int B256_RING = 4;
+constexpr int bwd_ws256_smem_bytes() { return 2 * B256_RING * B256_UNIT + 2 * 4 * 2048 + 2 * B256_RING * 32 * 4; }
+
+// common: a [32][256] unit straight to LDS, 512 threads x 2 sixteen-byte slots
+struct Unit256Dma {
+    unsigned voff[2];
+    FASN_DEV void init(int tid, int64_t row_stride) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ci = tid + i * 512;
+            const int r = ci >> 5, ch = (ci & 31) ^ swz_f<256>(r);
+            voff[i] = (unsigned)(r * (int)row_stride * 2 + ch * 16);
+        }
+    }
+    FASN_DEV void dma(u32x4 rw, uint32_t unit_addr_wave, int row0, int64_t row_stride) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16(rw, __builtin_amdgcn_readfirstlane(unit_addr_wave + i * 8192), voff[i], row0 * (int)row_stride * 2);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------ dK, dV
+template <typename Tag, int MODE>
+__global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdParams bp) {
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "two-wave D = 256 backward: plain and causal");
+    using E = ET<Tag>;
+    using vec8 = typename E::vec8;
+    const FwdParams& p = bp.f;
+    constexpr int D = 256, KS = 16, DB = 8, BN = 128, RU = 32;
+    constexpr bool causal = MODE == MODE_CAUSAL;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsQ = smem;                                              // [RING][UNIT]
+    char* const ldsDO = smem + B256_RING * B256_UNIT;                     // [RING][UNIT]
+    char* const ldsP = smem + 2 * B256_RING * B256_UNIT;                  // [2][4 key blocks][2 KiB]
+    float* const ldsLse = reinterpret_cast<float*>(ldsP + 2 * 4 * 2048);  // [RING][32]  -lse*log2e
+    float* const ldsDlt = ldsLse + B256_RING * 32;                        // [RING][32]  -delta
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+    const int role = wave >> 2;    // 0 = A (S, P, dV), 1 = B (dP, dS, dK)
+    const int kbw = wave & 3;
+
+    int bh, kblk;
+    block_to_work((int)blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
+    const int b = bh / p.H, h = bh % p.H;
+    const int kw0 = kblk * BN + kbw * 32;
+    const int key = kw0 + l31;
+    const int coff = p.Sk - p.Sq;
+    const float* lsebase = p.lse + (int64_t)bh * p.Sq;
+    const float* dltbase = bp.delta + (int64_t)bh * p.Sq;
+
+    const int nu_all = (p.Sq + RU - 1) / RU;
+    int u0 = 0;
+    if (causal) {
+        const int first_row = kblk * BN - coff;
+        u0 = first_row <= 0 ? 0 : first_row / RU;
+    }
+    const int nu = nu_all - u0;   // row units this workgroup walks (local index 0 .. nu-1 = rows 32 (u0 + u) ..)
+
+    Unit256Dma dq_, dd_;
+    dq_.init(tid, p.qs[2]);
+    dd_.init(tid, bp.dos[2]);
+    const u32x4 qrw = make_rsrc_words(p.q + (b * p.qs[0] + h * p.qs[1]) * 2, bp.qbytes);
+    const u32x4 drw = make_rsrc_words(bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2, bp.dobytes);
+    const uint32_t ldsQ_w = lds_addr(ldsQ) + wave * 1024, ldsDO_w = lds_addr(ldsDO) + wave * 1024;
+    // unit u: Q / dO images (2 + 2 requests per wave) and, by the first 32 threads of wave 4, its row statistics (negated: they are the
+    // start values of the S / dP accumulators; rows past Sq get -inf: every weight of such a row is 0)
+    float stL = 0.f, stX = 0.f;
+    const int stid = tid - 256;
+    auto requests = [&](int u) {   // (units past the end read back as zeros: the request counts stay uniform)
+        const int uu = u < nu ? u0 + u : nu_all + 8;
+        dq_.dma(qrw, ldsQ_w + (u & 3) * B256_UNIT, uu * RU, p.qs[2]);
+        dd_.dma(drw, ldsDO_w + (u & 3) * B256_UNIT, uu * RU, bp.dos[2]);
+    };
+    auto stats_gload = [&](int u) {
+        if (stid >= 0 && stid < RU) {
+            const int gr = (u0 + u) * RU + stid;
+            float l = INFINITY, x = 0.f;
+            if (u < nu && gr < p.Sq) {
+                l = lsebase[gr];
+                x = dltbase[gr];
+            }
+            stL = (l == -INFINITY || l == INFINITY) ? -INFINITY : -l * kLog2e;
+            stX = -x;
+        }
+    };
+    auto stats_lstore = [&](int u) {
+        if (stid >= 0 && stid < RU) {
+            ldsLse[(u & 3) * 32 + stid] = stL;
+            ldsDlt[(u & 3) * 32 + stid] = stX;
+        }
+    };
+
+    // this wave's operand fragment: K' = K * scale*log2e for A, V for B  (B operand: col = key, k = 8 features)
+    vec8 opf[KS];
+    {
+        const bool ok = key < p.Sk;
+        const char* rp = (role == 0 ? p.k + (b * p.ks[0] + h * p.ks[1] + (int64_t)key * p.ks[2]) * 2
+                                    : p.v + (b * p.vs[0] + h * p.vs[1] + (int64_t)key * p.vs[2]) * 2) + hi * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 a = {0u, 0u, 0u, 0u};
+            if (ok) a = gload16(rp + s * 32);
+            __builtin_memcpy(&opf[s], &a, 16);
+        }
+    }
+    f32x16 acc[DB];   // dV^T (A) or dK^T (B): [feature][key]
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+    if (nu > 0) {
+        // before the loop: units 0 and 1 with their statistics (iteration u requests unit u + 2)
+        requests(0);
+        stats_gload(0);
+        stats_lstore(0);
+        requests(1);
+        stats_gload(1);
+        stats_lstore(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) retire_loads(opf[s]);
+    if (role == 0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint16_t hk16[8];
+            __builtin_memcpy(hk16, &opf[s], 16);
+            f32x8 f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hk16[e]) * p.c;
+            opf[s] = E::cvt8(f);
+        }
+    }
+    char* const pslot = ldsP + kbw * 2048 + lane * 16;   // + parity * 8192 (+ 1024)
+    // Units above the causal diagonal of THIS wave's keys (at most three at the start of a key block's walk, the workgroup starts at
+    // its first visible row) are not skipped but masked like the diagonal itself, and a wave whose keys lie past Sk computes on zero
+    // operands (its rows are never stored): no skip paths, the unit bodies stay straight-line (with them hipcc spilled 113 registers).
+    auto needs_mask = [&](int u) { return causal && ((u0 + u) * RU + coff) < (kw0 + 31); };
+    auto unit_a = [&](const int u) {
+        const bool need_mask = needs_mask(u);
+        int ol = lane;   // an opaque copy of the lane id: the swizzled LDS addresses below are recomputed per unit instead of living in ~20
+        asm volatile("" : "+v"(ol));   // registers across the loop next to 192 persistent ones (a spilled address comes back through scratch with a vmcnt wait)
+        char* ps = pslot + (u & 1) * 8192;
+        const char* tQ = ldsQ + (u & 3) * B256_UNIT;
+        const char* tD = ldsDO + (u & 3) * B256_UNIT;
+        const float* tL = ldsLse + (u & 3) * 32;
+        const int r0 = (u0 + u) * RU;
+        f32x16 sacc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *LDS_PTR(const f32x4, tL + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sacc[4 * g + e] = a[e];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const vec8 qa = lds_read_rowfrag<E, D>(tQ, ol & 31, s, ol >> 5);
+            sacc = E::mfma(qa, opf[s], sacc);
+        }
+        if (need_mask) {   // the causal diagonal, on the scores (rows past Sq are hidden by their -inf seeds): a small in-place pass keeps the
+                           // exponential pass single (two instantiations of it cost this kernel 150 spilled registers)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                sacc[r] = key <= row + coff ? sacc[r] : -INFINITY;
+            }
+        }
+        vec8 pfr[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            f32x8 x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fast_exp2(sacc[8 * t2 + e]);
+            pfr[t2] = E::cvt8(x);
+        }
+        u32x4 w0, w1;
+        __builtin_memcpy(&w0, &pfr[0], 16);
+        __builtin_memcpy(&w1, &pfr[1], 16);
+        *LDS_PTR(u32x4, ps) = w0;
+        *LDS_PTR(u32x4, ps + 1024) = w1;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const vec8 dot = lds_read_trfrag<E, D>(tD, 16 * t2, d, ol);
+                acc[d] = E::mfma(dot, pfr[t2], acc[d]);
+            }
+    };
+    auto unit_b = [&](const int u) {
+        int ol = lane;
+        asm volatile("" : "+v"(ol));
+        const char* tQ = ldsQ + (u & 3) * B256_UNIT;
+        const char* tD = ldsDO + (u & 3) * B256_UNIT;
+        const float* tX = ldsDlt + (u & 3) * 32;
+        const char* ps = pslot + (u & 1) * 8192;
+        f32x16 pacc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 c = *LDS_PTR(const f32x4, tX + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pacc[4 * g + e] = c[e];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const vec8 da = lds_read_rowfrag<E, D>(tD, ol & 31, s, ol >> 5);
+            pacc = E::mfma(da, opf[s], pacc);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (P is fetched behind the dP chain: 8 registers less while the fragments stream)
+        const u32x4 w0 = *LDS_PTR(const u32x4, ps), w1 = *LDS_PTR(const u32x4, ps + 1024);
+        vec8 dsf[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            f32x8 x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t word = (t2 == 0 ? w0 : w1)[e >> 1];
+                const float pv = E::to_f32((uint16_t)((e & 1) ? (word >> 16) : (word & 0xffffu)));
+                x[e] = pv * pacc[8 * t2 + e];
+            }
+            dsf[t2] = E::cvt8(x);
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const vec8 qt = lds_read_trfrag<E, D>(tQ, 16 * t2, d, ol);
+                acc[d] = E::mfma(qt, dsf[t2], acc[d]);
+            }
+    };
+
+    // iteration u: A works on unit u, B on unit u - 1, unit u + 2 is requested (ring of four: its slot held unit u - 2, released by the
+    // barrier that ended iteration u - 1). Unit u + 1 - needed in iteration u + 1 - was requested in iteration u - 1: the wait that
+    // ends an iteration leaves this iteration's four requests in flight. (Wave 4's statistics loads are waited for by the compiler.)
+    if (nu > 0) {
+        auto run = [&](auto ROLE_) {
+            constexpr int ROLE = decltype(ROLE_)::value;
+            for (int u = 0; u <= nu; ++u) {
+                requests(u + 2);
+                if (ROLE == 1) stats_gload(u + 2);
+                if (ROLE == 0) {
+                    if (u < nu) unit_a(u);
+                } else {
+                    if (u > 0) unit_b(u - 1);
+                    stats_lstore(u + 2);
+                }
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                __syncthreads();
+            }
+        };
+        if (role == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (key < p.Sk) {
+        char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + h * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 2
+                             : bp.dk + (b * bp.dks[0] + h * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
+        const float sc = role == 0 ? 1.0f : bp.scale;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = acc[d][4 * g + e] * sc;
+                typename E::vec4 y = E::cvt4(x);
+                u32x2 raw;
+                __builtin_memcpy(&raw, &y, 8);
+                gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ dQ
+constexpr int bwd_dq_ws256_smem_bytes() { return 2 * B256_RING * B256_UNIT + 2 * 4 * 2048; }
+
+template <typename Tag, int MODE>
+__global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdParams bp) {
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "two-wave D = 256 backward: plain and causal");
+    using E = ET<Tag>;
+    using vec8 = typename E::vec8;
+    const FwdParams& p = bp.f;
+    constexpr int D = 256, KS = 16, DB = 8, BM = 128, KU = 32;
+    constexpr bool causal = MODE == MODE_CAUSAL;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsK = smem;                                   // [RING][UNIT]
+    char* const ldsV = smem + B256_RING * B256_UNIT;           // [RING][UNIT]
+    char* const ldsP = smem + 2 * B256_RING * B256_UNIT;       // [2][4 row blocks][2 KiB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+    const int role = wave >> 2;   // 0 = A (S^T, P^T), 1 = B (dP^T, dS^T, dQ^T)
+    const int rbw = wave & 3;
+
+    int bh, qi;
+    block_to_work((int)blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
+    const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qblk * BM;
+    const int qw0 = q0 + rbw * 32;
+    const int row = qw0 + l31;
+    const bool row_ok = row < p.Sq;
+    const int coff = p.Sk - p.Sq;
+    const int vis = causal ? row + coff : 0x7fffffff;
+
+    int nu = (p.Sk + KU - 1) / KU;
+    if (causal) {
+        const int kmax = min(q0 + BM, p.Sq) - 1 + coff;
+        nu = min(nu, kmax < 0 ? 0 : kmax / KU + 1);
+    }
+
+    Unit256Dma dk_, dv_;
+    dk_.init(tid, p.ks[2]);
+    dv_.init(tid, p.vs[2]);
+    const u32x4 krw = make_rsrc_words(p.k + (b * p.ks[0] + h * p.ks[1]) * 2, p.kbytes);
+    const u32x4 vrw = make_rsrc_words(p.v + (b * p.vs[0] + h * p.vs[1]) * 2, p.vbytes);
+    const uint32_t ldsK_w = lds_addr(ldsK) + wave * 1024, ldsV_w = lds_addr(ldsV) + wave * 1024;
+    const int past = (p.Sk + KU - 1) / KU + 8;
+    auto requests = [&](int u) {
+        const int uu = u < nu ? u : past;
+        dk_.dma(krw, ldsK_w + (u & 3) * B256_UNIT, uu * KU, p.ks[2]);
+        dv_.dma(vrw, ldsV_w + (u & 3) * B256_UNIT, uu * KU, p.vs[2]);
+    };
+
+    // this wave's operand fragment (B operand: col = q row, k = 8 features): Q' for A, dO for B; and its row statistic
+    vec8 opf[KS];
+    float stat = 0.f;
+    {
+        const char* rp = (role == 0 ? p.q + (b * p.qs[0] + h * p.qs[1] + (int64_t)row * p.qs[2]) * 2
+                                    : bp.dout + (b * bp.dos[0] + h * bp.dos[1] + (int64_t)row * bp.dos[2]) * 2) + hi * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 a = {0u, 0u, 0u, 0u};
+            if (row_ok) a = gload16(rp + s * 32);
+            __builtin_memcpy(&opf[s], &a, 16);
+        }
+        if (role == 0) {
+            const float l = row_ok ? p.lse[(int64_t)bh * p.Sq + row] : INFINITY;
+            stat = (l == -INFINITY || l == INFINITY) ? -INFINITY : -l * kLog2e;
+        } else {
+            stat = row_ok ? -bp.delta[(int64_t)bh * p.Sq + row] : 0.f;
+        }
+    }
+    if (nu > 0) {
+        requests(0);
+        requests(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) retire_loads(opf[s]);
+    retire_loads(stat);
+    if (role == 0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint16_t hq[8];
+            __builtin_memcpy(hq, &opf[s], 16);
+            f32x8 f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hq[e]) * p.c;
+            opf[s] = E::cvt8(f);
+        }
+    }
+    const int wave_first_vis = qw0 + coff, wave_last_vis = qw0 + 31 + coff;
+    auto classify = [&](int u, bool& skip, bool& need_mask) {
+        const int k0 = u * KU;
+        skip = qw0 >= p.Sq;
+        need_mask = k0 + KU > p.Sk;   // (a one-key K has row stride 0: its unit rows alias key 0, so keys past Sk are hidden explicitly)
+        if (causal) {
+            skip = skip || k0 > wave_last_vis;
+            need_mask = need_mask || (k0 + KU - 1) > wave_first_vis;
+        }
+    };
+    char* const pslot = ldsP + rbw * 2048 + lane * 16;
+
+    auto unit_a = [&](const int u) {
+        bool skip, need_mask;
+        classify(u, skip, need_mask);
+        int ol = lane;   // an opaque copy of the lane id: the swizzled LDS addresses below are recomputed per unit instead of living in ~20
+        asm volatile("" : "+v"(ol));   // registers across the loop next to 192 persistent ones (a spilled address comes back through scratch with a vmcnt wait)
+        char* ps = pslot + (u & 1) * 8192;
+        if (skip) {
+            *LDS_PTR(u32x4, ps) = u32x4{0u, 0u, 0u, 0u};
+            *LDS_PTR(u32x4, ps + 1024) = u32x4{0u, 0u, 0u, 0u};
+            return;
+        }
+        const char* tK = ldsK + (u & 3) * B256_UNIT;
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = stat;   // (a 16-register splat kept for the whole kernel would not fit next to 192)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const vec8 kf = lds_read_rowfrag<E, D>(tK, ol & 31, s, ol >> 5);
+            sacc = E::mfma(kf, opf[s], sacc);
+        }
+        if (need_mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = u * KU + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                sacc[r] = (key < p.Sk && key <= vis) ? sacc[r] : -INFINITY;
+            }
+        }
+        vec8 pfr[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            f32x8 x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fast_exp2(sacc[8 * t2 + e]);
+            pfr[t2] = E::cvt8(x);
+        }
+        u32x4 w0, w1;
+        __builtin_memcpy(&w0, &pfr[0], 16);
+        __builtin_memcpy(&w1, &pfr[1], 16);
+        *LDS_PTR(u32x4, ps) = w0;
+        *LDS_PTR(u32x4, ps + 1024) = w1;
+    };
+    auto unit_b = [&](const int u, f32x16 (&acc)[DB]) {
+        bool skip, need_mask;
+        classify(u, skip, need_mask);
+        int ol = lane;   // an opaque copy of the lane id: the swizzled LDS addresses below are recomputed per unit instead of living in ~20
+        asm volatile("" : "+v"(ol));   // registers across the loop next to 192 persistent ones (a spilled address comes back through scratch with a vmcnt wait)
+        if (skip) return;
+        const char* tK = ldsK + (u & 3) * B256_UNIT;
+        const char* tV = ldsV + (u & 3) * B256_UNIT;
+        const char* ps = pslot + (u & 1) * 8192;
+        const u32x4 w0 = *LDS_PTR(const u32x4, ps), w1 = *LDS_PTR(const u32x4, ps + 1024);
+        f32x16 pacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pacc[r] = stat;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const vec8 vf = lds_read_rowfrag<E, D>(tV, ol & 31, s, ol >> 5);
+            pacc = E::mfma(vf, opf[s], pacc);
+        }
+        vec8 dsf[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            f32x8 x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t word = (t2 == 0 ? w0 : w1)[e >> 1];
+                const float pv = E::to_f32((uint16_t)((e & 1) ? (word >> 16) : (word & 0xffffu)));
+                x[e] = pv * pacc[8 * t2 + e];
+            }
+            dsf[t2] = E::cvt8(x);
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const vec8 ktf = lds_read_trfrag<E, D>(tK, 16 * t2, d, ol);
+                acc[d] = E::mfma(ktf, dsf[t2], acc[d]);
+            }
+    };
+    auto close = [&]() {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+    };
+    if (role == 0) {
+        if (nu > 0)
+            for (int u = 0; u <= nu; ++u) {
+                requests(u + 2);
+                if (u < nu) unit_a(u);
+                close();
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        f32x16 acc[DB];   // dQ^T
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+        if (nu > 0)
+            for (int u = 0; u <= nu; ++u) {
+                requests(u + 2);
+                if (u > 0) unit_b(u - 1, acc);
+                close();
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (row_ok) {
+            char* rp = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1] + (int64_t)row * bp.dqs[2]) * 2;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = acc[d][4 * g + e] * bp.scale;
+                    typename E::vec4 y = E::cvt4(x);
+                    u32x2 raw;
+                    __builtin_memcpy(&raw, &y, 8);
+                    gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
+                }
+        }
+    }
+}
+
+}  // namespace fasn

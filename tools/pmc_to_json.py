@@ -48,7 +48,7 @@ for d in sorted(glob.glob(os.path.join(root, "*_*"))):
     if "SQ_INSTS_MFMA" in ctr and ent["kernel_ms_per_launch"] > 0:
         ent["mfma_insts"] = ctr["SQ_INSTS_MFMA"]
         ent["mfma_busy_vs_nominal_clock"] = ctr["SQ_INSTS_MFMA"] * 32 / (1024 * ent["kernel_ms_per_launch"] * 1e-3 * 2.4e9)
-    for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+    for c in ("GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
         if c in ctr:
             ent[c] = ctr[c]
     out[f"{w}:{p}"] = ent
