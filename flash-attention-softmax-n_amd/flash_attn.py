@@ -294,12 +294,20 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
                 a.dbias = _view4(dbias)
         else:
             a.dbias.ptr = None
+        def launch():
+            if pl.bwd_ws:
+                ws = torch.empty(pl.bwd_ws, dtype=torch.uint8, device=dev)
+                a.workspace, a.workspace_bytes = ws.data_ptr(), pl.bwd_ws
+            rc = lib.fasn_bwd(a, _stream_ptr(dev))
+            if rc:
+                _lib.check(rc, "fasn_bwd")
+
         try:
-            with torch.cuda.device(dev):
-                if pl.bwd_ws:
-                    ws = torch.empty(pl.bwd_ws, dtype=torch.uint8, device=dev)
-                    a.workspace, a.workspace_bytes = ws.data_ptr(), pl.bwd_ws
-                _lib.check(lib.fasn_bwd(a, _stream_ptr(dev)), "fasn_bwd")
+            if torch.cuda.current_device() == dev.index:   # the usual case: no device-guard object (about 10 us of host time per step)
+                launch()
+            else:
+                with torch.cuda.device(dev):
+                    launch()
         finally:   # the block is cached per call signature: whatever this call changed beyond pointers goes back, also when the launch raised
             if dout.stride() != o.stride():
                 a.dout = _view4(o)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (via gpurun): tools/prof_round4.sh TAG PART     PART = a (m0 c3 c4 c2 passes) | b (c5 d256, side kernels, bench lines, clocks)
+# usage (via gpurun): tools/prof_round4.sh TAG PART     PART = a (m0 c3 c4 c2 passes) | b (c5 d256, side kernels incl. their PMC pass, bench lines, clocks) | all (a + b without the side kernels: every BASELINE pass, pmc_latest.json and the bench lines from ONE library build)
 # Profiles of the product library as shipped (bench.py -> libfasn.so), one directory per workload:pass under gpurun_out/TAG:
 # rocprofv3 --kernel-trace --stats, then separate --pmc passes (never together with tracing domains other than kernel dispatch):
 # FETCH_SIZE, WRITE_SIZE, two SQ sets (the first one carries GRBM_GUI_ACTIVE: cycles per XCD summed over 8 -> the effective clock of
@@ -19,20 +19,23 @@ run() {   # run NAME "bench args" LAUNCHES counter-set...   (NAME = workload_pas
   find $D -name "*.db" -delete; find $D -type f -size +2M -delete
   echo "$n done: $(grep -c . $D/summary.txt) summary lines"
 }
-if [ "$PART" = "a" ]; then
+if [ "$PART" = "a" ] || [ "$PART" = "all" ]; then
   for w in m0 c3 c4; do for p in fwd bwd; do run ${w}_$p "--workload $w --pass $p" 40 FETCH_SIZE WRITE_SIZE "$SQ1" "$SQ2"; done; done
   for p in fwd bwd; do run c2_$p "--workload c2 --pass $p" 40 FETCH_SIZE WRITE_SIZE "$SQ1"; done
-else
+fi
+if [ "$PART" = "b" ] || [ "$PART" = "all" ]; then
   for p in fwd bwd; do run c5_$p "--workload c5 --pass $p" 8 FETCH_SIZE WRITE_SIZE "$SQ1"; done
   for p in fwd bwd; do run d256_$p "--workload d256 --pass $p" 20 FETCH_SIZE WRITE_SIZE "$SQ1"; done
   python3 $R/tools/pmc_to_json.py $O $R/flash-attention-softmax-n_amd/libfasn.so > $O/pmc_latest.json
   cp $O/pmc_latest.json $R/profiles/pmc_latest.json
+  if [ "$PART" = "b" ]; then
   # side kernels (softmax_n rows, moments, split-K decode, reduced bias gradient) and dropout: kernel trace + one SQ pass
   for s in bench_aux bench_dropout; do
     mkdir -p $O/$s; timeout 600 rocprofv3 --kernel-trace --stats -d $O/$s/kt -o kt -- python $R/tools/$s.py > $O/$s/out.log 2>&1
     timeout 900 rocprofv3 --pmc $SQ1 -d $O/$s/pmc_SQ -o pmc -- python $R/tools/$s.py > $O/$s/pmc.log 2>&1
     python3 $R/tools/pmc_summary.py $O/$s > $O/$s/summary.txt 2>&1; find $O/$s -name "*.db" -delete; find $O/$s -type f -size +2M -delete
   done
+  fi
   cd $R
   python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
   : > $O/bench_all.jsonl
