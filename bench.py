@@ -211,7 +211,7 @@ def timed(ctl, step, sync, steps, warmup, info=None):
         step()
     sync()
     pilot = max(time.perf_counter() - t0, 1e-6)
-    blocks = int(ctl.max(float(max(1, -(-MIN_TIMED_S // pilot)))))
+    blocks = int(ctl.max(float(max(1, -(-1.25 * MIN_TIMED_S // pilot)))))   # 25 % margin: the pilot block is often the slowest one
     blocks = min(blocks, 10000)
     ctl.barrier()
     sync()

@@ -1098,7 +1098,10 @@ def test_kernel_path_uses_the_arguments_of_the_real_call(pkg, dev):
     assert kernel_path(q, kv, kv, attn_mask=m) == "key-padding"
     b = torch.randn(4, 100, 96, device=dev, dtype=torch.bfloat16)
     assert kernel_path(q, kv, kv, attn_mask=m, attn_bias=b) == "vector bias + key-padding"
-    assert kernel_path(q, kv[:, :90], kv[:, :90], attn_bias=b[..., :90]) == "element-load (slow)"   # 180-byte bias rows are not 8-byte vectors
+    b90 = torch.randn(4, 100, 90, device=dev, dtype=torch.bfloat16)        # rows 180 bytes apart: not 8-byte vectors
+    with pytest.warns(RuntimeWarning):
+        assert kernel_path(q, kv[:, :90], kv[:, :90], attn_bias=b90) == "element-load (slow)"
+    assert kernel_path(q, kv[:, :90], kv[:, :90], attn_bias=b[..., :90]) != "element-load (slow)"   # a view with 192-byte rows is fine
     assert kernel_path(q.float(), kv.float(), kv.float()) == "fp32"
 
 
