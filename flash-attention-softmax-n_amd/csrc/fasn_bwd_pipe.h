@@ -380,6 +380,29 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
     }   // pass
 }
 
+// MFMA with its C / D operands in ARCHITECTURAL registers and its B operand in the accumulator half, as inline assembly: with 512
+// registers per lane hipcc selects the accumulator form for EVERY builtin MFMA and copies each S / dP tile out with 16 v_accvgpr_read
+// (272 moves per 64 MFMAs in the first build of the kernel below). The builtin (accumulator) form stays for dK / dV, which only
+// MFMAs touch. The hazard recogniser does not look inside an asm statement: results of these MFMAs are consumed one phase (>= 8
+// MFMAs) later, and mfma_guard() stands where a phase could be scheduled too close.
+template <typename Tag> struct MfmaV;
+template <> struct MfmaV<bf16_tag> {
+    template <typename V> static FASN_DEV void first(f32x16& d, const V& a, const V& b, const f32x16& c) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+    }
+    template <typename V> static FASN_DEV void next(f32x16& d, const V& a, const V& b) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    }
+};
+template <> struct MfmaV<f16_tag> {
+    template <typename V> static FASN_DEV void first(f32x16& d, const V& a, const V& b, const f32x16& c) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+    }
+    template <typename V> static FASN_DEV void next(f32x16& d, const V& a, const V& b) {
+        asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // The same pipeline with KB 32-key blocks per wave and ONE wave per SIMD (512 registers: the dK / dV accumulators and the K / V
 // fragments, which only MFMAs touch, can live in the accumulator half of the file). Every Q / dO fragment and every row-statistics
@@ -524,6 +547,18 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dkdv_pipe2_kernel(const BwdPa
     vec8 pk[KB][2], dsk[KB][2];    // 16-bit P, dS of that block
 #define FASN_SB() __builtin_amdgcn_sched_barrier(0)
     auto pin = [](auto& x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); };
+    auto pin_a = [](auto& x) __attribute__((always_inline)) { asm volatile("" : "+a"(x)); };   // the value lives in the accumulator half of the file HERE
+    auto pin_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) pin_a(dkacc[kb][d]), pin_a(dvacc[kb][d]);
+    };
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pin_a(kf[kb][s]), pin_a(vf[kb][s]);
+    pin_acc();
 
     auto load_rf_q = [&](int bo, int qb) __attribute__((always_inline)) {
         const char* tQ = ldsQ + bo;
@@ -551,19 +586,19 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dkdv_pipe2_kernel(const BwdPa
     };
     auto mfma_S1 = [&](f32x16 (&s)[KB]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) s[kb] = E::mfma(qa[0], kf[kb][0], lr);
+        for (int kb = 0; kb < KB; ++kb) MfmaV<Tag>::first(s[kb], qa[0], kf[kb][0], lr);
 #pragma unroll
         for (int ks = 1; ks < KS; ++ks)
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) s[kb] = E::mfma(qa[ks], kf[kb][ks], s[kb]);
+            for (int kb = 0; kb < KB; ++kb) MfmaV<Tag>::next(s[kb], qa[ks], kf[kb][ks]);
     };
     auto mfma_S2 = [&](f32x16 (&pp)[KB]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) pp[kb] = E::mfma(da[0], vf[kb][0], xr);
+        for (int kb = 0; kb < KB; ++kb) MfmaV<Tag>::first(pp[kb], da[0], vf[kb][0], xr);
 #pragma unroll
         for (int ks = 1; ks < KS; ++ks)
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) pp[kb] = E::mfma(da[ks], vf[kb][ks], pp[kb]);
+            for (int kb = 0; kb < KB; ++kb) MfmaV<Tag>::next(pp[kb], da[ks], vf[kb][ks]);
     };
     auto load_tr = [&](int bo, int qb, int t2) __attribute__((always_inline)) {
         const char* tQ = ldsQ + bo;
@@ -585,14 +620,14 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dkdv_pipe2_kernel(const BwdPa
     };
     auto elem_half = [&](f32x16 (&s)[KB], f32x16 (&pp)[KB], int half) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = 8 * half + rr;
-                const float pv = fast_exp2(s[kb][r]);
-                s[kb][r] = pv;
-                pp[kb][r] = pv * pp[kb][r];
-            }
+            for (int rr = 0; rr < 8; ++rr) s[kb][8 * half + rr] = fast_exp2(s[kb][8 * half + rr]);
+            // dP' comes from an asm MFMA (no hazard bookkeeping by the compiler): its first reader stands behind the eight exponentials
+            asm volatile("s_nop 3" : "+v"(s[kb]), "+v"(pp[kb]));
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) pp[kb][8 * half + rr] *= s[kb][8 * half + rr];
+        }
     };
     auto pack = [&](const f32x16 (&s)[KB], const f32x16 (&pp)[KB]) __attribute__((always_inline)) {
 #pragma unroll
@@ -637,6 +672,9 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dkdv_pipe2_kernel(const BwdPa
         mfma_S2(pp);
         FASN_SB();
         if (hp) load_tr(pbo, pqb, 1);
+        // the row statistics are the untied C operand of asm MFMAs, read over the MFMA's passes: their registers stay allocated until
+        // here (the compiler believes an asm statement is done when it has issued and would hand them to the next VALU result)
+        asm volatile("" ::"v"(lr), "v"(xr));
         FASN_SB();
     };
     auto phase_b = [&](auto HAVE_PREV, f32x16 (&s)[KB], f32x16 (&pp)[KB], int r0, int nbo, int nqb) __attribute__((always_inline)) {
@@ -677,6 +715,7 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dkdv_pipe2_kernel(const BwdPa
             }
         }
         phase_b(TrueT{}, sY, pY, r0 + 32, bo_next, 0);
+        pin_acc();
         bo = bo_next;
     };
     tile_body(0, TrueT{});
