@@ -1158,6 +1158,38 @@ def test_attn_bias_gradient_reduced_in_kernel(pkg, dev, kind, D, dtype):
         _check(got, want, dtype, f"{kind}/{nm}")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("kind", ["hls", "hls+causal", "hls+keypad", "11ls+keypad+causal", "b1ls"])
+def test_attn_bias_gradient_with_more_tiles_than_workgroups(pkg, dev, kind, D, dtype):
+    """The two-role bias-gradient kernel (csrc/fasn_bwd_dbias_ws.h) is persistent: a workgroup walks several [128 x 128] tiles and its
+    K / V stream, its row prefetches and the lagging wave B run across the tile boundaries. More tiles than the chip has CUs, ragged
+    sizes (a last tile with one 64-key unit, rows past Sq), tiles a causal mask hides completely (zero-filled), key padding that hides a
+    whole unit of some batch elements, and reductions over the batch, over the heads and over both."""
+    B, H, L, S = 2, 3, 1300, 1480
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    gen = torch.Generator().manual_seed(13)
+    shape = {"hls": (H, L, S), "hls+causal": (H, L, S), "hls+keypad": (H, L, S), "11ls+keypad+causal": (1, 1, L, S), "b1ls": (B, 1, L, S)}[kind]
+    bias = torch.randn(*shape, generator=gen).to(dtype).to(dev).requires_grad_()
+    mask = None
+    if "keypad" in kind:
+        mask = torch.ones(B, 1, 1, S, dtype=torch.bool)
+        mask[0, ..., 1100:] = False      # the last three key blocks of batch element 0 hidden, one of them from its middle
+        mask[1, ..., 300:333] = False
+        mask = mask.to(dev)
+    causal = "causal" in kind
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, attn_bias=bias, attn_mask=mask, is_causal=causal)
+    out.backward(do)
+    qc, kc, vc, bc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v, bias))
+    o = ref_attention_n(qc, kc, vc, softmax_n_param=1.0, attn_bias=bc, attn_mask=None if mask is None else mask.cpu(), is_causal=causal)
+    o.backward(do.cpu().float())
+    _check(out, o, dtype, f"{kind}/out")
+    _check(bias.grad, bc.grad, dtype, f"{kind}/dbias")
+    if causal:   # (L < S: the causal diagonal ends at key L - 1 + S - L; everything right of a row's last visible key is exactly zero)
+        assert float(bias.grad[..., 0, S - L + 1:].float().abs().max()) == 0.0
+
+
 def test_alibi_gradient_at_config4_size_without_a_dense_buffer(pkg, dev):
     """(4,32,8192,128) with the dense ALiBi bias [H,L,S] (4.3 GB) requiring a gradient: the backward must not allocate the
     [B,H,L,S] dS tensor (17 GB) - its extra memory stays under 6 GB - and sampled rows of dbias match the oracle."""
