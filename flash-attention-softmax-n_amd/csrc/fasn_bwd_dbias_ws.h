@@ -10,14 +10,22 @@
 // of a tile: the workgroup is persistent, the step sequence runs over all of its tiles, so the K / V stream never drains (the first
 // version, fasn_bwd_dbias_kernel, waited for a 32 KiB tile it had requested one 0.5 us step earlier, 8200 times per CU at config 4).
 //   * K and V units come by LDS-DMA into rings of three: K a whole step (two units) ahead of wave A, V two units ahead of wave B.
-//   * Everything a lane owns per ROW - its Q' / dO fragments, LSE / delta, the bias values of the tile, the mask bytes - comes straight
-//     from global memory into registers, requested a step before it is needed by inline-asm loads (a builtin load would make hipcc put
-//     `s_waitcnt vmcnt(0)` in front of the first use and drain the K / V stream with it). Such a load is issued, waited for (the
-//     counted `s_waitcnt` that ends every iteration) and handed to the compiler (`retire`) inside ONE iteration, into a register that is
-//     an in/out operand of the statement: no copy of a value that has not arrived yet can be scheduled.
+//   * A lane owns a query ROW. Its Q' / dO fragments come by LDS-DMA in coalesced pieces into an 8 KiB bounce area the two waves of a
+//     pair share (D = 128 then uses all 160 KiB of LDS): B asks for its step's dO rows at the start of the step's first iteration, A
+//     for the next step's Q rows at the start of the second, and each moves them into its operand registers at the end of the same
+//     iteration, when the MFMAs that used the previous fragments are done. The finished gradient tile leaves through the same area
+//     as full 256-byte rows. (Per-lane 16-byte loads of the fragments cost the vector L1 64 accesses per instruction.)
+//   * The small per-row things - LSE / delta, the tile's bias values, the mask bytes - are inline-asm loads into registers (a builtin
+//     load would make hipcc put `s_waitcnt vmcnt(0)` in front of the first use and drain the K / V stream with it): issued, waited for
+//     (the counted `s_waitcnt` that ends every iteration) and handed to the compiler (`retire`) inside ONE iteration, into a register
+//     that is an in/out operand of the statement, so no copy of a value that has not arrived yet can be scheduled.
 //   * One barrier per unit publishes P^T (two buffers) and the landed K / V units.
 //   * The kernel has its own lean parameter block, and what only a new step or a new tile needs is re-read from the kernel-argument
 //     segment there instead of living in scalar registers through the loop (the first version spilled 220 of them to vector lanes).
+// What bounds it (config 4: 9.8 ms against 17.8, `profiles/r04_bias_gradient_*`): a step moves 128 KiB into the CU (64 KiB of rows, 64 KiB
+// of K / V) for 64 MFMAs per SIMD, the CU has at most its LDS in flight, and a request takes ~3 us under this load: 37 GB/s per CU.
+// Removing the MFMAs, the exponentials, the barriers or half of the requests each changes the time by less than 15 % (ablations in
+// the same profile file); a variant with every request two iterations ahead needed 30 registers more than a wave has and was slower.
 // Tiles no (b,h) can see (causal) are zero-filled before the walk; a unit nobody can see inside a visible tile is walked with P = 0.
 // No atomics, no [B,H,L,S] buffer, deterministic.
 #pragma once
@@ -41,7 +49,7 @@ struct DbwParams {
 
 template <int D>
 constexpr int dbias_ws_smem_bytes() {
-    return 6 * KT * D * 2 + 2 * 16384;
+    return 6 * KT * D * 2 + 2 * 16384 + 4 * 8192;   // K ring, V ring, two P buffers, one 8 KiB bounce area per wave pair (D = 128: all 160 KiB)
 }
 
 // asynchronous register loads (see above): OFF is the immediate byte offset; rows / keys outside the descriptor's range read as zero
@@ -72,6 +80,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
     char* const ldsK = smem;                // [3][TILEB]
     char* const ldsV = smem + 3 * TILEB;    // [3][TILEB]
     char* const ldsP = smem + 6 * TILEB;    // [2][PBUF]
+    char* const ldsR = smem + 6 * TILEB + 2 * PBUF;   // [4 wave pairs][8 KiB]: row images on their way to registers, gradient tiles on their way out
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -222,34 +231,42 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
     k_dma(cur, 1, 1);
     v_dma(cur, 0, 0);
 
-    // this wave's operand fragments (B operand: col = q row, k = 8 features): Q' for wave A, dO for wave B; raw rows of the NEXT step
+    // this wave's operand fragments (B operand: col = q row, k = 8 features): Q' for wave A, dO for wave B
     vec8 opf[KS];
-    u32x4 nraw[KS];
     uint32_t nstat = 0u;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) nraw[s] = u32x4{0u, 0u, 0u, 0u};
     float stat = 0.f;
-    auto rows_request = [&](const Step& s) {   // Q (A) or dO (B) rows and the row statistic of a step
+    // Q (wave A) / dO (wave B) rows of a step: the wave's 32 rows come by LDS-DMA in coalesced 16-byte pieces into the pair's bounce area
+    // (a swizzled [32][D] image, rows past Sq read back as zeros) and go on to registers at the end of the same iteration, when the
+    // MFMAs that used the previous fragments are done: B asks for its step's dO in the first iteration of the step, A for the next
+    // step's Q in the second. The row statistic (LSE / delta) is one asynchronous register load.
+    constexpr int NR = (32 * CPR) / 64;
+    char* const bounce = ldsR + rbw * 8192;
+    const uint32_t bounce_a = lds_addr(bounce);
+    unsigned voffR[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int ci = lane + i * 64;
+        const int r = ci / CPR, ch = (ci % CPR) ^ swz_f<D>(r);
+        voffR[i] = (unsigned)(r * (role == 0 ? p.qs2 : p.dos2) * 2 + ch * 16);
+    }
+    auto rows_request = [&](const Step& s) {
         CP kp = rare();
-        const int row = s.qblk * 128 + rbw * 32 + l31;
+        const int row0 = s.qblk * 128 + rbw * 32;
         const int64_t bh = (int64_t)s.b * kp->H + s.h;
         const int Sq = kp->Sq;
+        u32x4 rw;
+        int soff;
         if (role == 0) {
-            const u32x4 rw = make_rsrc_words(kp->q + (s.b * kp->qs0 + s.h * kp->qs1) * 2, kp->qbytes);
-            const uint32_t vo = (uint32_t)(row * kp->qs2 * 2 + hi * 16);
-            [&]<int... S>(std::integer_sequence<int, S...>) { (aload16<S * 32>(nraw[S], rw, vo), ...); }(std::make_integer_sequence<int, KS>{});
-            aload4(nstat, make_rsrc_words(kp->lse + bh * Sq, (uint32_t)Sq * 4u), (uint32_t)row * 4u);
+            rw = make_rsrc_words(kp->q + (s.b * kp->qs0 + s.h * kp->qs1) * 2, kp->qbytes);
+            soff = row0 * kp->qs2 * 2;
+            aload4(nstat, make_rsrc_words(kp->lse + bh * Sq, (uint32_t)Sq * 4u), (uint32_t)(row0 + l31) * 4u);
         } else {
-            const u32x4 rw = make_rsrc_words(kp->dout + (s.b * kp->dos0 + s.h * kp->dos1) * 2, kp->dobytes);
-            const uint32_t vo = (uint32_t)(row * kp->dos2 * 2 + hi * 16);
-            [&]<int... S>(std::integer_sequence<int, S...>) { (aload16<S * 32>(nraw[S], rw, vo), ...); }(std::make_integer_sequence<int, KS>{});
-            aload4(nstat, make_rsrc_words(kp->delta + bh * Sq, (uint32_t)Sq * 4u), (uint32_t)row * 4u);
+            rw = make_rsrc_words(kp->dout + (s.b * kp->dos0 + s.h * kp->dos1) * 2, kp->dobytes);
+            soff = row0 * kp->dos2 * 2;
+            aload4(nstat, make_rsrc_words(kp->delta + bh * Sq, (uint32_t)Sq * 4u), (uint32_t)(row0 + l31) * 4u);
         }
-    };
-    auto rows_retire = [&]() {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) retire_loads(nraw[s]);
-        retire_loads(nstat);
+        for (int i = 0; i < NR; ++i) lds_dma16(rw, __builtin_amdgcn_readfirstlane(bounce_a + i * 1024), voffR[i], soff);
     };
     int s0 = 0;   // ring slot of the current step's first unit: (2 * steps done) % 3
     auto end_iteration = [&](bool in_flight) {
@@ -266,10 +283,9 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) nbias[t][kb][g] = braw[t][kb][g] = u32x4{0u, 0u, 0u, 0u};
-            }
         auto a_request = [&](const Step& s) {   // everything wave A needs for a step, and for its tile if the step opens one
             rows_request(s);
             CP kp = rare();
@@ -292,34 +308,33 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
                 aload16<208>(nbias[1][1][1], brw, vo);
             }
         };
-        auto a_retire = [&]() {
-            rows_retire();
+        auto a_take = [&](const Step& s) {   // behind the counted wait: what was requested becomes the operands of step s
+            const int row = s.qblk * 128 + rbw * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {   // Q' = Q * scale*log2e, rounded to the operand type as in every vector kernel
+                const u32x4 raw = *LDS_PTR(const u32x4, bounce + tile_off<D>(l31, 2 * ks + hi));
+                uint16_t hq[8];
+                __builtin_memcpy(hq, &raw, 16);
+                f32x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hq[e]) * p.c;
+                opf[ks] = E::cvt8(f);
+            }
+            retire_loads(nstat);
+            const float l = __uint_as_float(nstat);
+            stat = (row >= p.Sq || l == -INFINITY || l == INFINITY) ? -INFINITY : -l * kLog2e;   // a row without weights: P = 0
             retire_loads(nmk[0]);
             retire_loads(nmk[1]);
+            if (p.mask != nullptr) {
+                kpw[0] = __ballot(nmk[0] != 0u);
+                kpw[1] = __ballot(nmk[1] != 0u);
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int g = 0; g < 2; ++g) retire_loads(nbias[t][kb][g]);
-        };
-        auto a_consume = [&](const Step& s) {   // the requested values become the operands of the step
-            const int row = s.qblk * 128 + rbw * 32 + l31;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {   // Q' = Q * scale*log2e, rounded to the operand type as in every vector kernel
-                uint16_t hq[8];
-                __builtin_memcpy(hq, &nraw[ks], 16);
-                f32x8 f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = E::to_f32(hq[e]) * p.c;
-                opf[ks] = E::cvt8(f);
-            }
-            const float l = __uint_as_float(nstat);
-            stat = (row >= p.Sq || l == -INFINITY || l == INFINITY) ? -INFINITY : -l * kLog2e;   // a row without weights: P = 0
-            if (p.mask != nullptr) {
-                kpw[0] = __ballot(nmk[0] != 0u);
-                kpw[1] = __ballot(nmk[1] != 0u);
-            }
             if (s.fl & 4) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -382,27 +397,26 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
 
         a_request(cur);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        a_retire();
+        a_take(cur);
         __syncthreads();
         while (cur.fl & 1) {
             const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;
             const bool more = (nxt.fl & 1) != 0;
-            // ---- iteration (step, unit 0): A on unit 0, B on unit 1 of the previous step
-            a_consume(cur);
-            if (more) a_request(nxt);
+            // ---- iteration (step, unit 0): A on unit 0, B on unit 1 of the previous step (the bounce area is B's)
             if (more) k_dma(nxt, 0, s2);
             v_dma(cur, 1, s1);
             a_unit(cur, std::integral_constant<int, 0>{}, s0);
             end_iteration(more);
-            a_retire();
             __syncthreads();
-            // ---- iteration (step, unit 1): A on unit 1, B on unit 0
+            // ---- iteration (step, unit 1): A on unit 1, B on unit 0; A asks for the next step's operands and takes them at the end
             if (more) {
+                a_request(nxt);
                 k_dma(nxt, 1, s0);
                 v_dma(nxt, 0, s2);
             }
             a_unit(cur, std::integral_constant<int, 1>{}, s1);
             end_iteration(more);
+            if (more) a_take(nxt);
             __syncthreads();
             cur = nxt;
             advance(nxt);
@@ -421,10 +435,14 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
         f32x16 seed;   // -delta of the lane's row in every register: start value of dP'
 #pragma unroll
         for (int r = 0; r < 16; ++r) seed[r] = 0.f;
-        auto b_consume = [&](const Step& s) {
+        auto b_take = [&](const Step& s) {   // behind the counted wait: the dO fragments and -delta of step s
             const int row = s.qblk * 128 + rbw * 32 + l31;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) __builtin_memcpy(&opf[ks], &nraw[ks], 16);
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 raw = *LDS_PTR(const u32x4, bounce + tile_off<D>(l31, 2 * ks + hi));
+                __builtin_memcpy(&opf[ks], &raw, 16);
+            }
+            retire_loads(nstat);
             stat = row < p.Sq ? -__uint_as_float(nstat) : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) seed[r] = stat;
@@ -449,14 +467,12 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
                 }
             }
         };
-        // A complete tile leaves in two steps: b_pack converts it to the bias's dtype into 32 holding registers (and zeroes the sums) right
-        // behind its last unit, b_store writes them - 16 bytes = 8 keys per store - at the START of the next iteration, in front of that
-        // iteration's K / V requests: `vmcnt` retires in order, so stores issued behind the requests would make the counted wait at the
-        // end of the iteration wait for the requests themselves.
-        vec8 hold[2][2][2];
-        Step pend = cur;
-        pend.fl = 0;
-        auto b_pack = [&]() {
+        // A complete tile leaves through the pair's bounce area as a [32 rows][128 keys] image in the bias's dtype, read back as full
+        // 256-byte rows (16 bytes = 8 keys per lane and store), and the sums start again from zero. It is called at the END of an iteration,
+        // behind the counted wait and the pick-up of this wave's dO rows: stores issued in front of the iteration's K / V requests would
+        // be waited for with them (`vmcnt` retires in order), these have the whole next iteration.
+        auto b_store = [&](const Step& s) {
+            CP kp = rare();
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -469,68 +485,49 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
                             x[e] = dsum[t][kb][8 * g + e];
                             dsum[t][kb][8 * g + e] = 0.f;
                         }
-                        hold[t][kb][g] = E::cvt8(x);
+                        const vec8 y = E::cvt8(x);
+                        u32x4 w;
+                        __builtin_memcpy(&w, &y, 16);
+                        *LDS_PTR(u32x4, bounce + tile_off<128>(l31, t * 8 + kb * 4 + 2 * hi + g)) = w;
                     }
-        };
-        auto b_store = [&](const Step& s) {
-            CP kp = rare();
-            const int row = s.qblk * 128 + rbw * 32 + l31;
-            char* const orow = kp->dbias + (s.bb * kp->dbs0 + s.hb * kp->dbs1 + (int64_t)row * kp->dbs2) * 2;
+            char* const obase = kp->dbias + (s.bb * kp->dbs0 + s.hb * kp->dbs1) * 2;
+            const int dbs2 = kp->dbs2;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const int key = s.kblk * 128 + t * KT + kb * 32 + 16 * hi + 8 * g;
-                        if (row >= p.Sq || key >= p.Sk) continue;
-                        if (key + 8 <= p.Sk) {
-                            u32x4 w;
-                            __builtin_memcpy(&w, &hold[t][kb][g], 16);
-                            gstore16(orow + key * 2, w);
-                        } else {
-                            uint16_t hv[8];
-                            __builtin_memcpy(hv, &hold[t][kb][g], 16);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                if (key + e < p.Sk) reinterpret_cast<uint16_t*>(orow)[key + e] = hv[e];
-                        }
-                    }
+            for (int i = 0; i < 8; ++i) {
+                const int ci = lane + i * 64, r = ci >> 4, c = ci & 15;
+                const u32x4 w = *LDS_PTR(const u32x4, bounce + tile_off<128>(r, c));
+                const int row = s.qblk * 128 + rbw * 32 + r, key = s.kblk * 128 + c * 8;
+                if (row >= p.Sq || key >= p.Sk) continue;
+                char* o = obase + ((int64_t)row * dbs2 + key) * 2;
+                if (key + 8 <= p.Sk) {
+                    gstore16(o, w);
+                } else {
+                    for (int e = 0; e < 8 && key + e < p.Sk; ++e) reinterpret_cast<uint16_t*>(o)[e] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+                }
+            }
         };
 
-        rows_request(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        rows_retire();
-        __syncthreads();
+        __syncthreads();   // (wave A's first operands)
         while (cur.fl & 1) {
             const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;
             const bool more = (nxt.fl & 1) != 0;
-            // ---- iteration (step, unit 0): B finishes the previous step (its unit 1 sits in V slot (2j - 1) % 3 = s2)
+            // ---- iteration (step, unit 0): B finishes the previous step (its unit 1 sits in V slot (2j - 1) % 3 = s2), asks for this
+            // step's dO rows and takes them at the end; a finished tile leaves behind them
+            rows_request(cur);
             if (more) k_dma(nxt, 0, s2);
             v_dma(cur, 1, s1);
-            if (prv.fl & 1) {
-                b_unit(std::integral_constant<int, 1>{}, s2);
-                if (prv.fl & 8) {
-                    b_pack();
-                    pend = prv;
-                }
-            }
+            if (prv.fl & 1) b_unit(std::integral_constant<int, 1>{}, s2);
             end_iteration(more);
+            b_take(cur);
+            if ((prv.fl & 9) == 9) b_store(prv);
             __syncthreads();
-            // ---- iteration (step, unit 1): B starts this step
-            if (pend.fl & 1) {
-                b_store(pend);
-                pend.fl = 0;
-            }
-            b_consume(cur);
-            if (more) rows_request(nxt);
+            // ---- iteration (step, unit 1): B on unit 0 of this step
             if (more) {
                 k_dma(nxt, 1, s0);
                 v_dma(nxt, 0, s2);
             }
             b_unit(std::integral_constant<int, 0>{}, s0);
             end_iteration(more);
-            rows_retire();
             __syncthreads();
             prv = cur;
             cur = nxt;
@@ -538,7 +535,6 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
             s0 = s2;
         }
         b_unit(std::integral_constant<int, 1>{}, s0 == 0 ? 2 : s0 - 1);   // unit 1 of the last step
-        b_pack();
         b_store(prv);
         __syncthreads();
     }

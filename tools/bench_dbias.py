@@ -1,5 +1,5 @@
 """bias gradient reduced in the kernel (fasn_bwd_dbias) at BASELINE config 4's size: forward + backward with and without a bias that
-needs a gradient, and the one-pass backward A/B at M0 (tools/fused_check.sh has the harness version)"""
+needs a gradient"""
 import sys, torch
 sys.path.insert(0, '/root/repo')
 import flash_attention_softmax_n_amd as pkg
