@@ -58,15 +58,31 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     const int rbw = wave & 3;     // 32-row block of this wave inside the workgroup's 128 rows
     const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
 
-    int bh, qi;
+    // Ragged key-padded batch under a batch-broadcast bias (config 4): like the forward (fasn_fwd_kernel.h, kpair_plan) a workgroup takes
+    // the r-th longest and then the r-th shortest batch element, so that every workgroup of the launch walks about the same number of
+    // tiles (the in-order dispatcher makes a round as long as its longest workgroup: 19 % idle CUs here). The second element runs through
+    // a second inlined copy of the body - no loop-carried state (a pass loop cost 18 spilled registers in round 3).
+    constexpr bool KPAIR = KP && VBIAS && !DROP;
+    int bh0, qi0, bh2 = -1;
     if (VBIAS && p.batch_inner && (p.H & 7) == 0) {   // the B workgroups that read the same bias rows run together on one XCD
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int bb = j % p.B, rest = j / p.B;
-        qi = rest % bp.nblk;
-        bh = bb * p.H + (rest / bp.nblk) * 8 + xcd;
+        int bb = j % p.B, rest = j / p.B;
+        if constexpr (KPAIR) {
+            int b0 = -1, b1 = -1;
+            if (kpair_plan(p, smem, tid, j % ((p.B + 1) / 2), b0, b1)) {
+                const int np = (p.B + 1) / 2;
+                if (j >= (p.H >> 3) * bp.nblk * np) return;
+                rest = j / np;
+                bb = b0;
+                if (b1 != b0) bh2 = b1 * p.H + (rest / bp.nblk) * 8 + xcd;
+            }
+        }
+        qi0 = rest % bp.nblk;
+        bh0 = bb * p.H + (rest / bp.nblk) * 8 + xcd;
     } else {
-        block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
+        block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh0, qi0);
     }
+    auto item = [&](const int bh, const int qi) __attribute__((always_inline)) {
     const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
     const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
@@ -425,6 +441,14 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
                 __builtin_memcpy(&raw, &y, 8);
                 gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
             }
+    }
+    };   // item
+    item(bh0, qi0);
+    if constexpr (KPAIR) {
+        if (bh2 >= 0) {
+            __syncthreads();   // every wave is done with the first element's LDS
+            item(bh2, qi0);
+        }
     }
 }
 
