@@ -40,6 +40,7 @@ static int launch_ws(const DbiasParams& dp, hipStream_t s) {
     const long tiles = (long)dp.Bb * dp.Hb * dp.nqb * dp.nkb;
     const int grid = (int)(tiles < n ? tiles : n);
     w.dk = grid % dp.nkb, w.dq = (grid / dp.nkb) % dp.nqb, w.dh = (grid / (dp.nkb * dp.nqb)) % dp.Hb, w.db = grid / (dp.nkb * dp.nqb * dp.Hb);
+    w.xorder = (grid == 256 && dp.Hb % 8 == 0 && dp.nkb % 8 == 0 && dp.nqb % 4 == 0 && !(FASN_BWD_VARIANT & 4096)) ? 1 : 0;   // (developer library: bit 12 = plain tile order)
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, s, w);
     return launch_rc();
 }

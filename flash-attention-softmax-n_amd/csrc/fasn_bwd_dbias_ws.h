@@ -45,6 +45,7 @@ struct DbwParams {
     float c;                // scale * log2(e)
     int Bb, Hb, nqb, nkb;   // extent of the bias over batch / heads (1 = reduce over it), 128-row / 128-key blocks
     int dk, dq, dh, db;     // the grid size as digits of the tile index (kblk fastest, then qblk, hb, bb)
+    int xorder;             // 1: XCD-local tile order (256 workgroups, Hb % 8 == 0, nkb % 8 == 0, nqb % 4 == 0), see next_tile
 };
 
 template <int D>
@@ -136,7 +137,21 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
         int tile, j, b, h, qblk, kblk, hb, bb, fl;
     };
     auto flags_of = [&](const Step& s) { return s.tile < ntiles ? (1 | (s.j == 0 ? 4 : 0) | (s.j == nsteps - 1 ? 8 : 0)) : 0; };
+    // Tile order. Workgroup i runs on XCD i % 8 (its own L2). Plain order: tiles i, i + grid, ... of the (bb, hb, qblk, kblk) index - an XCD
+    // then owns an eighth of the key blocks and reads EVERY query row of every head (8 x the Q / dO bytes in L2 misses: 27 % of the L2
+    // requests at config 4). XCD-local order (xorder): XCD x owns the heads x, x + 8, ...; its 32 workgroups cover 8 key blocks x 4 query
+    // blocks of one head at a time and march through the query blocks first (the 8 key blocks' K / V of all batch elements stay in
+    // the L2), then through the key-block groups (the head's rows come back from the memory-side cache), then to the next head.
+    const int xl = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
     auto first_step = [&](Step& s) {
+        if (p.xorder) {
+            s.tile = 0;
+            s.kblk = xl & 7;
+            s.qblk = xl >> 3;
+            s.hb = xcd;
+            s.bb = 0;
+            return;
+        }
         int r = s.tile = blockIdx.x;
         s.kblk = r % p.nkb;
         r /= p.nkb;
@@ -147,6 +162,22 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dbias_ws_kernel(const DbwPara
     };
     auto next_tile = [&](Step& s) {   // tile += gridDim.x in mixed radix (no division), then on to the next tile somebody can see
         do {
+            if (p.xorder) {
+                s.qblk += 4;
+                if (s.qblk >= p.nqb) {
+                    s.qblk = xl >> 3;
+                    s.kblk += 8;
+                    if (s.kblk >= p.nkb) {
+                        s.kblk = xl & 7;
+                        s.hb += 8;
+                        if (s.hb >= p.Hb) {
+                            s.hb = xcd;
+                            if (++s.bb >= p.Bb) s.tile = ntiles;
+                        }
+                    }
+                }
+                continue;
+            }
             s.tile += (int)gridDim.x;
             s.kblk += p.dk;
             int cy = s.kblk >= p.nkb;

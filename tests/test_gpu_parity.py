@@ -1190,6 +1190,29 @@ def test_attn_bias_gradient_with_more_tiles_than_workgroups(pkg, dev, kind, D, d
         assert float(bias.grad[..., 0, S - L + 1:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("kind", ["hls", "hls+keypad+causal"])
+def test_attn_bias_gradient_in_xcd_local_tile_order(pkg, dev, kind, D):
+    """8 heads, 8 x 8 tiles per head, 512 tiles on 256 workgroups: the launch that takes the XCD-local tile order of
+    csrc/fasn_bwd_dbias_ws.h (an XCD owns the heads h % 8 and walks query blocks, then key-block groups, then heads)."""
+    B, H, L, S, dtype = 2, 8, 1024, 1024, torch.bfloat16
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    bias = torch.randn(H, L, S, generator=torch.Generator().manual_seed(17)).to(dtype).to(dev).requires_grad_()
+    mask = None
+    if "keypad" in kind:
+        mask = torch.ones(B, 1, 1, S, dtype=torch.bool)
+        mask[1, ..., 700:] = False
+        mask = mask.to(dev)
+    causal = "causal" in kind
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, attn_bias=bias, attn_mask=mask, is_causal=causal)
+    out.backward(do)
+    qc, kc, vc, bc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v, bias))
+    o = ref_attention_n(qc, kc, vc, softmax_n_param=1.0, attn_bias=bc, attn_mask=None if mask is None else mask.cpu(), is_causal=causal)
+    o.backward(do.cpu().float())
+    _check(bias.grad, bc.grad, dtype, f"{kind}/dbias")
+
+
 def test_alibi_gradient_at_config4_size_without_a_dense_buffer(pkg, dev):
     """(4,32,8192,128) with the dense ALiBi bias [H,L,S] (4.3 GB) requiring a gradient: the backward must not allocate the
     [B,H,L,S] dS tensor (17 GB) - its extra memory stays under 6 GB - and sampled rows of dbias match the oracle."""
