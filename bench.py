@@ -212,6 +212,8 @@ def timed(ctl, step, sync, steps, warmup, info=None):
     sync()
     pilot = max(time.perf_counter() - t0, 1e-6)
     blocks = int(ctl.max(float(max(1, -(-1.25 * MIN_TIMED_S // pilot)))))   # 25 % margin: the pilot block is often the slowest one
+    if MIN_TIMED_S <= 0.0:
+        blocks = 1
     blocks = min(blocks, 10000)
     ctl.barrier()
     sync()
@@ -238,9 +240,12 @@ def main():
     ap.add_argument("--roofline-launches", type=int, default=0,
                     help="back-to-back launches of the roofline loop (default: 200 forward / 60 backward; counter passes of the profile scripts use fewer)")
     ap.add_argument("--no-extra-passes", action="store_true", help="default forward run: skip the backward / fwdbwd objects")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0,
+                    help="shortest timed region (default 50 ms; the counter passes of the profile scripts pass 0: exactly K timed steps, counters serialise the launches)")
     ap.add_argument("--stub-step-ms", type=float, default=None,
                     help="testing only: replace the GPU step by a sleep of this many ms (exercises launch + aggregation on CPU)")
     args = ap.parse_args()
+    globals()["MIN_TIMED_S"] = args.min_timed_ms * 1e-3
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
 
