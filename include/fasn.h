@@ -122,7 +122,7 @@ typedef struct fasn_bwd_args {
                           Dense form: dS as [B,H,Sq,Sk] in `dtype` (the dQ kernels store it; the caller sums over whatever its
                           bias broadcasts). Reduced form (ABI 4): a batch and / or head stride of 0 (with B > 1 / H > 1) asks for the
                           sum over that dimension - dbias is then [1 or B, 1 or H, Sq, Sk], written once by a kernel that walks
-                          the (b,h) sharing each bias tile (csrc/fasn_bwd_dbias.h; 16-bit q/k/v, no dropout; no [B,H,Sq,Sk]
+                          the (b,h) sharing each bias tile (csrc/fasn_bwd_dbias_ws.h / fasn_bwd_dbias.h; 16-bit q/k/v, no dropout; no [B,H,Sq,Sk]
                           buffer anywhere). */
     int32_t flags;     /* ABI 4: FASN_BWD_* bits, 0 = default */
     int32_t dbias_dtype; /* ABI 4, reduced form only: FASN_BIAS_SAME (0 means the same) = `dtype`, FASN_BIAS_F32 = fp32 elements */
