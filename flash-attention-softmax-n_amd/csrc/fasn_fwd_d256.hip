@@ -25,12 +25,13 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.variant == 1) {   // A/B: the round-3 feature-half kernels
         if (mode == MODE_PLAIN) return launch_fwd_one<Tag, 256, 1, MODE_PLAIN, 1, 4, 0, 2, 0, 2>(p, s);
         if (mode == MODE_CAUSAL) return launch_fwd_one<Tag, 256, 1, MODE_CAUSAL, 1, 4, 0, 2, 0, 2>(p, s);
+        if (mode == MODE_KEYPAD) return launch_fwd_one<Tag, 256, 1, MODE_KEYPAD, 1, 4, 0, 2, 0, 2>(p, s);
     }
 #endif
     switch (mode) {
         case MODE_PLAIN: return launch_ws256<Tag, MODE_PLAIN>(p, s);
         case MODE_CAUSAL: return launch_ws256<Tag, MODE_CAUSAL>(p, s);
-        case MODE_KEYPAD: return launch_fwd_one<Tag, 256, 1, MODE_KEYPAD, 1, 4, 0, 2, 0, 2>(p, s);
+        case MODE_KEYPAD: return launch_ws256<Tag, MODE_KEYPAD>(p, s);
         case MODE_GENERAL: case MODE_GENERAL_B: case MODE_GENERAL_M: return launch_fwd_one<Tag, 256, 1, MODE_GENERAL, 1, 4, 0, 2, 0, 2>(p, s);
         default: return launch_fwd_one<Tag, 256, 1, MODE_GENERAL_SLOW, 1, 4, 0, 0, 0, 2>(p, s);
     }

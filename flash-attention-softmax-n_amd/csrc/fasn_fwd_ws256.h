@@ -22,21 +22,23 @@ namespace fasn {
 
 constexpr int W256_NK = 4, W256_NV = 4;           // K / V ring slots
 constexpr int W256_UNIT = 32 * 256 * 2;           // one 32-key image
-constexpr int ws256_smem_bytes() { return (W256_NK + W256_NV) * W256_UNIT + 2 * 4 * 2048 + 2 * 4 * 256; }
+constexpr int ws256_smem_bytes() { return (W256_NK + W256_NV) * W256_UNIT + 2 * 4 * 2048 + 2 * 4 * 256 + kFwdKpMaxTiles * 8; }
 
 template <typename Tag, int MODE>
 __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams p) {
-    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "two-wave D = 256 forward: plain and causal");
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL || MODE == MODE_KEYPAD, "two-wave D = 256 forward: plain, causal, key padding");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     constexpr int D = 256, KS = 16, DB = 8, BM = 128, KU = 32;
-    constexpr bool causal = MODE == MODE_CAUSAL;
+    constexpr bool KP = MODE == MODE_KEYPAD;   // a boolean mask over (batch, head, key), with or without the causal flag
+    const bool causal = MODE == MODE_CAUSAL || (KP && p.causal != 0);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsK = smem;                                        // [W256_NK][UNIT]
     char* const ldsV = smem + W256_NK * W256_UNIT;                  // [W256_NV][UNIT]
     char* const ldsP = smem + (W256_NK + W256_NV) * W256_UNIT;      // [2][4 row blocks][2 KiB]
     float* const ldsA = reinterpret_cast<float*>(ldsP + 2 * 4 * 2048);   // [2][4][64] rescale factor of the lane's row
+    uint64_t* const ldsKP = reinterpret_cast<uint64_t*>(ldsP + 2 * 4 * 2048 + 2 * 4 * 256);   // [kFwdKpMaxTiles] visibility words of 64 keys (key-padding mode)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -97,13 +99,19 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
     float l_run = (p.n > 0.f && hi == 0) ? p.n : 0.f;
     const int wave_first_vis = qw0 + coff, wave_last_vis = qw0 + 31 + coff;
     // wave-uniform classification of (this wave's 32 rows) x (key block u): identical for the A and the B wave of a row block
-    auto classify = [&](int u, bool& skip, bool& need_mask) {
+    auto classify = [&](int u, bool& skip, bool& need_mask, uint32_t& kpb) {
         const int k0 = u * KU;
         skip = qw0 >= p.Sq;
         need_mask = k0 + KU > p.Sk;
+        kpb = ~0u;
         if (causal) {
             skip = skip || k0 > wave_last_vis;
             need_mask = need_mask || (k0 + KU - 1) > wave_first_vis;
+        }
+        if (KP) {   // the 32 visibility bits of this key block
+            kpb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ldsKP[u >> 1] >> (32 * (u & 1))));
+            skip = skip || kpb == 0u;
+            need_mask = need_mask || kpb != ~0u;
         }
     };
     char* const pslot = ldsP + rbw * 2048 + lane * 16;      // + parity * 8192 (+ 1024 for the second half of the block)
@@ -112,7 +120,8 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
     // ---- wave A: key block u
     auto block_a = [&](const int u, const int kslot, const vec8 (&qf)[KS]) {
         bool skip, need_mask;
-        classify(u, skip, need_mask);
+        uint32_t kpb;
+        classify(u, skip, need_mask, kpb);
         char* ps = pslot + (u & 1) * 8192;
         if (skip) {   // nothing visible to these rows: B is told to leave its accumulator alone and gets zero weights
             *LDS_PTR(u32x4, ps) = u32x4{0u, 0u, 0u, 0u};
@@ -132,8 +141,8 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
         if (need_mask) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = u * KU + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                sacc[r] = (key < p.Sk && key <= vis) ? sacc[r] : -INFINITY;
+                const int kin = (r & 3) + 8 * (r >> 2) + 4 * hi, key = u * KU + kin;
+                sacc[r] = (key < p.Sk && key <= vis && (!KP || ((kpb >> kin) & 1u))) ? sacc[r] : -INFINITY;
             }
         }
         float tmax = sacc[0];
@@ -170,7 +179,8 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
         const u32x4 w0 = *LDS_PTR(const u32x4, ps), w1 = *LDS_PTR(const u32x4, ps + 1024);
         const float alpha = aslot[(u & 1) * 256];
         bool skip, need_mask;
-        classify(u, skip, need_mask);
+        uint32_t kpb;
+        classify(u, skip, need_mask, kpb);
         if (skip) return;
         if (__any(alpha != 1.0f)) {   // some row's running maximum moved (every row in the first blocks, rarely later)
 #pragma unroll
@@ -203,6 +213,18 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
     };
+    if (KP) kp_build_words(ldsKP, p.mask ? p.mask + (b * p.ms[0] + h * p.ms[1]) : nullptr, p.Sk, (p.Sk + 63) / 64, tid, 512);   // published by the first barrier below
+    auto trim = [&]() {   // key-padding: blocks behind the last visible key are not walked (every wave finds the same one)
+        if (!KP) return;
+        int last = -1;
+        for (int t = lane; t < (p.Sk + 63) / 64; t += 64) {
+            const uint64_t w = ldsKP[t];
+            if (w != 0ull) last = 2 * t + ((w >> 32) != 0ull ? 1 : 0);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
+        nu = min(nu, __builtin_amdgcn_readfirstlane(last + 1));
+    };
     if (role == 0) {
         vec8 qf[KS];
         {
@@ -216,6 +238,7 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        trim();
 #pragma unroll
         for (int s = 0; s < KS; ++s) {   // Q' = Q * scale*log2e, rounded to the operand type (as core/flash_attn.py:81-83 does with its pre-scaled q)
             retire_loads(qf[s]);
@@ -247,6 +270,7 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
             for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        trim();
         for (int u = 0; u <= nu; ++u) {
             requests(u);
             if (u > 0) block_b(u - 1, (u - 1) & 3, oacc);

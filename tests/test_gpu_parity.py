@@ -1301,7 +1301,7 @@ def test_ragged_key_padded_batch_under_a_broadcast_bias_is_length_paired(pkg, de
 
 
 # ---------------------------------------------------------------- key-padding masks (MODE_KEYPAD, MODE_BIAS_KEYPAD)
-@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("D", [32, 64, 128, 256])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("pattern", ["tail", "random", "blocks", "none_visible_in_one_batch"])
 @pytest.mark.parametrize("n", [1.0, 0.0])
