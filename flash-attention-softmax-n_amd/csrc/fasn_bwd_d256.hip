@@ -1,11 +1,13 @@
 // D = 256 backward instantiations: the one-wave dQ and dK/dV kernels with the whole register file (one wave per SIMD:
 // dQ^T is 128 accumulator registers next to 128 of Q / dO fragments; dK^T + dV^T would be 256 next to 128 of K / V fragments, so
 // the dK/dV kernel runs as two workgroups per key block that each own half of the features, DH = 2).
-// Key padding rides the plain kernels; dense masks, bias and dropout take the element-load kernels.
+// Key padding: the two-wave kernels too (kvg == 1), else the plain one-wave kernels; dense masks, bias and dropout take the element-load kernels.
 #include "fasn_bwd_launch.h"
 #include "fasn_bwd_ws256.h"
 namespace fasn {
 // plain / causal without dropout or grouped K/V: the two-wave kernels of fasn_bwd_ws256.h (round 4): delta, dQ, dK/dV
+// MODE = the dQ kernel's; MODE_KEYPAD (a boolean mask over (batch, head, key), p.f.causal as it comes): the dK/dV kernel then is the
+// plain or causal one with the mask pointer set - it writes the rows of hidden keys as zeros (fasn_bwd_ws256.h)
 template <typename Tag, int MODE>
 static int launch_ws256(BwdParams p, hipStream_t s) {
     constexpr int D = 256;
@@ -25,9 +27,15 @@ static int launch_ws256(BwdParams p, hipStream_t s) {
     {
         constexpr int smem = bwd_ws256_smem_bytes();
         p.nblk = (p.f.Sk + 127) / 128;
-        constexpr auto kern = &fasn_bwd_dkdv_ws256_kernel<Tag, MODE>;
-        ensure_smem<kern>(smem);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+        if (MODE == MODE_CAUSAL || (MODE == MODE_KEYPAD && p.f.causal)) {
+            constexpr auto kern = &fasn_bwd_dkdv_ws256_kernel<Tag, MODE_CAUSAL>;
+            ensure_smem<kern>(smem);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+        } else {
+            constexpr auto kern = &fasn_bwd_dkdv_ws256_kernel<Tag, MODE_PLAIN>;
+            ensure_smem<kern>(smem);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+        }
     }
     return launch_rc();
 }
@@ -38,6 +46,7 @@ static int go(const BwdParams& p, int mode, hipStream_t s) {
     if (p.f.kvg == 1 && !(FASN_BWD_VARIANT & 1)) {   // (developer library: bwd_variant bit 0 = the round-3 feature-half kernels, for A/B)
         if (mode == MODE_PLAIN) return launch_ws256<Tag, MODE_PLAIN>(p, s);
         if (mode == MODE_CAUSAL) return launch_ws256<Tag, MODE_CAUSAL>(p, s);
+        if (mode == MODE_KEYPAD && p.f.ms[3] == 1 && (p.f.Sk + 63) / 64 <= kDq256KpTiles) return launch_ws256<Tag, MODE_KEYPAD>(p, s);
     }
     switch (mode) {
         case MODE_CAUSAL: return launch_bwd_one<Tag, 256, 1, 1, MODE_CAUSAL, 1, 1, 0, 0, 2>(p, s);

@@ -10,7 +10,7 @@
 //                               wave B:  dP'^T = V dO^T (seeded with -delta), reads P^T -> dS^T = P^T o dP'^T -> dQ^T += K^T dS^T
 //
 // Every wave holds ONE output accumulator (128 registers) and ONE operand fragment set (64): 7 GEMM-equivalents executed, no spills.
-// B runs one unit behind A; plain and causal launches without dropout, one query head per K/V head (the rest keeps the one-wave kernels).
+// B runs one unit behind A; plain, causal and key-padding launches without dropout, one query head per K/V head (the rest keeps the one-wave kernels).
 #pragma once
 #include "fasn_bwd_kernel.h"
 
@@ -280,14 +280,17 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
     if (key < p.Sk) {
         char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + h * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 2
                              : bp.dk + (b * bp.dks[0] + h * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
-        const float sc = role == 0 ? 1.0f : bp.scale;
+        // key-padding launches (a mask over (batch, head, key), fasn_bwd_d256.hip) run this kernel unchanged: a hidden key's column of
+        // scores touches nothing but its own dK / dV rows (LSE and delta already exclude it), so it is enough to write those as zeros
+        const bool hidden = p.mask != nullptr && p.mask[b * p.ms[0] + h * p.ms[1] + key] == 0;
+        const float sc = hidden ? 0.f : (role == 0 ? 1.0f : bp.scale);
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 x;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = acc[d][4 * g + e] * sc;
+                for (int e = 0; e < 4; ++e) x[e] = hidden ? 0.f : acc[d][4 * g + e] * sc;   // (a hidden column may hold inf / NaN)
                 typename E::vec4 y = E::cvt4(x);
                 u32x2 raw;
                 __builtin_memcpy(&raw, &y, 8);
@@ -297,21 +300,24 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
 }
 
 // ------------------------------------------------------------------------------------------------------------------ dQ
-constexpr int bwd_dq_ws256_smem_bytes() { return 2 * B256_RING * B256_UNIT + 2 * 4 * 2048; }
+constexpr int kDq256KpTiles = 1024;   // visibility words of 64 keys kept in LDS by the key-padding instantiation (8 KiB): Sk <= 65536
+constexpr int bwd_dq_ws256_smem_bytes() { return 2 * B256_RING * B256_UNIT + 2 * 4 * 2048 + kDq256KpTiles * 8; }
 
 template <typename Tag, int MODE>
 __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdParams bp) {
-    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "two-wave D = 256 backward: plain and causal");
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL || MODE == MODE_KEYPAD, "two-wave D = 256 backward: plain, causal, key padding");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     const FwdParams& p = bp.f;
     constexpr int D = 256, KS = 16, DB = 8, BM = 128, KU = 32;
-    constexpr bool causal = MODE == MODE_CAUSAL;
+    constexpr bool KP = MODE == MODE_KEYPAD;   // a boolean mask over (batch, head, key), with or without the causal flag
+    const bool causal = MODE == MODE_CAUSAL || (KP && p.causal != 0);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsK = smem;                                   // [RING][UNIT]
     char* const ldsV = smem + B256_RING * B256_UNIT;           // [RING][UNIT]
     char* const ldsP = smem + 2 * B256_RING * B256_UNIT;       // [2][4 row blocks][2 KiB]
+    uint64_t* const ldsKP = reinterpret_cast<uint64_t*>(smem + 2 * B256_RING * B256_UNIT + 2 * 4 * 2048);   // [kDq256KpTiles]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -374,11 +380,33 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
         requests(0);
         requests(1);
     }
+    if (KP) kp_build_words(ldsKP, p.mask ? p.mask + (b * p.ms[0] + h * p.ms[1]) : nullptr, p.Sk, (p.Sk + 63) / 64, tid, 512);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < KS; ++s) retire_loads(opf[s]);
     retire_loads(stat);
+    if (KP) {   // blocks behind the last visible key are not walked (every wave finds the same one; the two units requested above stay harmless)
+        int last = -1;
+        for (int t = lane; t < (p.Sk + 63) / 64; t += 64) {
+            const uint64_t w = ldsKP[t];
+            if (w != 0ull) last = 2 * t + ((w >> 32) != 0ull ? 1 : 0);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
+        const int was = nu;
+        nu = min(nu, __builtin_amdgcn_readfirstlane(last + 1));
+        if (was > 0 && nu == 0) {   // nothing visible at all: dQ = 0
+            if (role == 1 && row_ok) {
+                char* rp = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1] + (int64_t)row * bp.dqs[2]) * 2;
+#pragma unroll
+                for (int c = 0; c < D / 8; ++c)
+                    if ((c & 1) == hi) gstore16(rp + c * 16, u32x4{0u, 0u, 0u, 0u});
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+    }
     if (role == 0) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -391,20 +419,27 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
         }
     }
     const int wave_first_vis = qw0 + coff, wave_last_vis = qw0 + 31 + coff;
-    auto classify = [&](int u, bool& skip, bool& need_mask) {
+    auto classify = [&](int u, bool& skip, bool& need_mask, uint32_t& kpb) {
         const int k0 = u * KU;
         skip = qw0 >= p.Sq;
         need_mask = k0 + KU > p.Sk;   // (a one-key K has row stride 0: its unit rows alias key 0, so keys past Sk are hidden explicitly)
+        kpb = ~0u;
         if (causal) {
             skip = skip || k0 > wave_last_vis;
             need_mask = need_mask || (k0 + KU - 1) > wave_first_vis;
+        }
+        if (KP) {
+            kpb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ldsKP[u >> 1] >> (32 * (u & 1))));
+            skip = skip || kpb == 0u;
+            need_mask = need_mask || kpb != ~0u;
         }
     };
     char* const pslot = ldsP + rbw * 2048 + lane * 16;
 
     auto unit_a = [&](const int u) {
         bool skip, need_mask;
-        classify(u, skip, need_mask);
+        uint32_t kpb;
+        classify(u, skip, need_mask, kpb);
         int ol = lane;   // an opaque copy of the lane id: the swizzled LDS addresses below are recomputed per unit instead of living in ~20
         asm volatile("" : "+v"(ol));   // registers across the loop next to 192 persistent ones (a spilled address comes back through scratch with a vmcnt wait)
         char* ps = pslot + (u & 1) * 8192;
@@ -425,8 +460,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
         if (need_mask) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = u * KU + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                sacc[r] = (key < p.Sk && key <= vis) ? sacc[r] : -INFINITY;
+                const int kin = (r & 3) + 8 * (r >> 2) + 4 * hi, key = u * KU + kin;
+                sacc[r] = (key < p.Sk && key <= vis && (!KP || ((kpb >> kin) & 1u))) ? sacc[r] : -INFINITY;
             }
         }
         vec8 pfr[2];
@@ -445,7 +480,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
     };
     auto unit_b = [&](const int u, f32x16 (&acc)[DB]) {
         bool skip, need_mask;
-        classify(u, skip, need_mask);
+        uint32_t kpb;
+        classify(u, skip, need_mask, kpb);
         int ol = lane;   // an opaque copy of the lane id: the swizzled LDS addresses below are recomputed per unit instead of living in ~20
         asm volatile("" : "+v"(ol));   // registers across the loop next to 192 persistent ones (a spilled address comes back through scratch with a vmcnt wait)
         if (skip) return;

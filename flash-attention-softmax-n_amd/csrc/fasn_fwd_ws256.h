@@ -13,8 +13,9 @@
 // each per 32-key block, no score computed twice. B runs one key block behind A: the P^T of block u is published by the barrier
 // that ends iteration u. K / V arrive by LDS-DMA in units of 32 keys (16 KiB images [32][256], swizzled like every tile), K and V in rings
 // of four, both requested two blocks ahead of their first reader (vmcnt counts in order: a deeper K ring behind a shallow V ring would
-// be drained by the wait for V anyway); one barrier per block. Plain and causal launches (the key-padding / bias /
-// dropout modes stay on the feature-half kernels).
+// be drained by the wait for V anyway); one barrier per block. Plain, causal and key-padding launches (MODE_KEYPAD: wave A takes
+// the 32 visibility bits of a key block from a per-workgroup word table and the blocks behind the last visible key are not walked);
+// the bias / dropout modes stay on the feature-half kernels.
 #pragma once
 #include "fasn_fwd_kernel.h"
 
