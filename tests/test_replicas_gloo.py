@@ -72,6 +72,14 @@ def test_bench_py_launches_its_own_two_replicas():
     assert [x["rank"] for x in pr] == [0, 1] and 9.0 <= pr[0]["ms_per_step"] <= 20.0 and abs(pr[1]["ms_per_step"] - t) < 1e-6
 
 
+def test_bench_py_counter_pass_mode_runs_exactly_k_steps():
+    """--min-timed-ms 0 (the counter passes of tools/prof_round4.sh: hardware counters serialise the launches) switches the 50 ms rule off"""
+    r, lines = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--stub-step-ms", "1",
+                            "--min-timed-ms", "0"], env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr
+    assert lines[0]["steps"] == 3 and lines[0]["timed_steps"] == 3
+
+
 def test_bench_py_times_at_least_50_ms():
     """K steps of 1 ms would be a 3 ms timed region: the region is repeated in whole blocks of K until it lasts >= 50 ms, `steps` stays K"""
     r, lines = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--stub-step-ms", "1"],
