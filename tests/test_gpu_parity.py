@@ -964,7 +964,8 @@ def _random_case2(rng):
     S = int(rng.choice([5, 65, 200, 256, 512, 776, 1100, 1536]))
     return dict(D=D, B=B, H=H, L=L, S=S, causal=bool(rng.integers(0, 2)), n=float(rng.choice([0.5, 1.0, 3.0])),
                 mask_kind=str(rng.choice(["none", "keypad", "keypad", "keypad_holes"])), bias_kind=str(rng.choice(["none", "none", "hls", "1hls", "b1ls", "11ls"])),
-                bias_grad=bool(rng.integers(0, 2)), dtype=[torch.float16, torch.bfloat16][int(rng.integers(0, 2))])
+                bias_grad=bool(rng.integers(0, 2)), dtype=[torch.float16, torch.bfloat16][int(rng.integers(0, 2))],
+                layout=str(rng.choice(["bhld", "bhld", "blhd", "padded"])), do_layout=str(rng.choice(["bhld", "blhd"])))
 
 
 _FUZZ2 = int(os.environ.get("FASN_FUZZ_SEEDS", "60"))
@@ -978,8 +979,8 @@ def test_randomized_round4_kernel_families(pkg, dev, seed):
     rng = np.random.default_rng(7000 + seed)
     c = _random_case2(rng)
     B, H, L, S, D, dtype = c["B"], c["H"], c["L"], c["S"], c["D"], c["dtype"]
-    q, k, v = (_rand(sh, dtype, dev, sd).requires_grad_() for sh, sd in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
-    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    q, k, v = (_make(sh, dtype, dev, sd, c["layout"]).detach().requires_grad_() for sh, sd in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _make((B, H, L, D), dtype, dev, 4, c["do_layout"]) * 2.0   # (std 1; a [B,L,H,D] gradient arrives with its own strides)
     gen = torch.Generator().manual_seed(seed)
     mask = bias = None
     if c["mask_kind"].startswith("keypad"):
