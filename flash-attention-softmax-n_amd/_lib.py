@@ -10,17 +10,18 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasn.so")
 
-FASN_ABI_VERSION = 4
+FASN_ABI_VERSION = 5
 FASN_BWD_ONE_PASS = 1
 FASN_DTYPE_F16, FASN_DTYPE_BF16, FASN_DTYPE_F32 = 0, 1, 2
 FASN_BIAS_NONE, FASN_BIAS_SAME, FASN_BIAS_F32 = 0, 1, 2
 FASN_PATH_NAMES = {0: "plain", 1: "key-padding", 2: "vector mask/bias", 3: "vector bias + key-padding", 4: "element-load (slow)", 5: "fp32"}
 FASN_PATH_ELEMENT = 4
+FASN_PLAN_FWD, FASN_PLAN_BWD, FASN_PLAN_FWD_WS = 0, 1, 2
 
 # every entry point include/fasn.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "fasn_abi_version", "fasn_strerror", "fasn_supported", "fasn_fwd", "fasn_fwd_path", "fasn_fwd_workspace_bytes", "fasn_fwd_ws",
-    "fasn_bwd_workspace_bytes", "fasn_bwd", "fasn_rng_advance",
+    "fasn_bwd_workspace_bytes", "fasn_bwd", "fasn_rng_advance", "fasn_launch_plan",
     "fasn_softmax_n_fwd", "fasn_softmax_n_bwd", "fasn_moments",
 )
 
@@ -93,6 +94,8 @@ def load():
     lib.fasn_rng_advance.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
     lib.fasn_bwd_workspace_bytes.restype = c_size_t
     lib.fasn_bwd_workspace_bytes.argtypes = [POINTER(BwdArgs)]
+    lib.fasn_launch_plan.restype = c_int32
+    lib.fasn_launch_plan.argtypes = [POINTER(BwdArgs), c_int32, c_char_p, c_size_t]
     lib.fasn_softmax_n_fwd.restype = c_int32
     lib.fasn_softmax_n_fwd.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_float, c_int32, c_void_p]
     lib.fasn_softmax_n_bwd.restype = c_int32
@@ -104,6 +107,21 @@ def load():
         raise ImportError(f"libfasn ABI version {ver} != expected {FASN_ABI_VERSION}; rebuild csrc/")
     _lib = lib
     return lib
+
+
+def launch_plan(args, which):
+    """The kernels fasn_fwd (FASN_PLAN_FWD), fasn_bwd (FASN_PLAN_BWD) or fasn_fwd_ws (FASN_PLAN_FWD_WS) would launch for `args` (a BwdArgs;
+    the forward plans read only its .fwd part): a list of (kernel name with template arguments, grid, block, lds bytes). Nothing is
+    launched and no device is touched (include/fasn.h: fasn_launch_plan)."""
+    buf = ctypes.create_string_buffer(8192)
+    rc = load().fasn_launch_plan(args, which, buf, len(buf))
+    if rc < 0:
+        check(rc, "fasn_launch_plan")
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, g, b, l = line.rsplit(" ", 3)
+        out.append((name, int(g.split("=")[1]), int(b.split("=")[1]), int(l.split("=")[1])))
+    return out
 
 
 def check(rc, what):

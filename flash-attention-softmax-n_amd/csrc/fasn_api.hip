@@ -2,6 +2,10 @@
 // No allocation, no synchronisation, no environment variables: every exported symbol is declared in include/fasn.h.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cxxabi.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include "fasn.h"
 #include "fasn_launch.h"
 #include "fasn_bwd_launch.h"
@@ -13,7 +17,37 @@ namespace fasn {
 int g_bwd_variant = 0;
 unsigned long long* g_timeline = nullptr;
 int g_pair_mode = -1;
+int g_kprot = 1;
 #endif
+thread_local LaunchLog* t_launch_log = nullptr;
+// one line per launch: the kernel with its template arguments (demangled from the type name kernel_pretty_name<&kernel<...>> hands over:
+// "fasn::KernelTag<&(void fasn::kernel<arguments>(fasn::Params))>"), grid, block, LDS
+void log_launch(const char* tag_name, unsigned grid, unsigned block, int smem) {
+    LaunchLog* const g = t_launch_log;
+    if (g == nullptr) return;
+    int st = 0;
+    char* dm = abi::__cxa_demangle(tag_name, nullptr, nullptr, &st);
+    const char* b = dm ? strstr(dm, "&(void ") : nullptr;
+    b = b ? b + 7 : (dm ? dm : tag_name);
+    if (strncmp(b, "fasn::", 6) == 0) b += 6;
+    size_t n = 0;
+    for (int depth = 0; b[n] != 0; ++n) {   // the name ends at the parameter list: the first '(' outside the template arguments
+        if (b[n] == '<') ++depth;
+        else if (b[n] == '>') --depth;
+        else if (b[n] == '(' && depth == 0) break;
+    }
+    char tail[96];
+    const int tn = snprintf(tail, sizeof tail, " grid=%u block=%u lds=%d\n", grid, block, smem);
+    if (g->len + n + (size_t)tn + 1 > g->cap) {   // does not fit: remember that by moving len past cap (the caller reports FASN_EINVAL)
+        g->len = g->cap + 1;
+    } else {
+        memcpy(g->buf + g->len, b, n);
+        memcpy(g->buf + g->len + n, tail, (size_t)tn);
+        g->len += n + (size_t)tn;
+        g->buf[g->len] = 0;
+    }
+    free(dm);
+}
 int launch_fwd_f32(const FwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_f32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 }  // namespace fasn
@@ -151,6 +185,11 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     p.timeline = g_timeline;
 #endif
     p.pair = 0;   // set per launch (paired causal blocks, fasn_launch.h)
+#ifdef FASN_DEV_VARIANTS
+    p.kprot = g_kprot;
+#else
+    p.kprot = 1;
+#endif
     p.nsplit = 1;
     p.tps = 0;
     p.part_o = nullptr;
@@ -298,6 +337,7 @@ int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_byt
 void fasn_dev_set_bwd_variant(int v) { fasn::g_bwd_variant = v; }
 void fasn_dev_set_timeline(unsigned long long* buf) { fasn::g_timeline = buf; }
 void fasn_dev_set_pair_mode(int v) { fasn::g_pair_mode = v; }
+void fasn_dev_set_kprot(int v) { fasn::g_kprot = v; }
 // developer library only (tools/libfasn_dev.so): forward with an explicit tuning variant, used by tools/fasn_harness
 int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant) {
     FwdParams p;
@@ -404,6 +444,21 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
         return launch_bwd_dbias(p, l, a->dbias.stride[0] == 0 ? 1 : a->fwd.B, a->dbias.stride[1] == 0 ? 1 : a->fwd.H, dbias_f32, (hipStream_t)stream);
     }
     return launch_bwd(p, l, (hipStream_t)stream);
+}
+
+int fasn_launch_plan(const fasn_bwd_args* args, int32_t which, char* buf, size_t cap) {
+    if (args == nullptr || buf == nullptr || cap == 0 || which < FASN_PLAN_FWD || which > FASN_PLAN_FWD_WS) return FASN_EINVAL;
+    LaunchLog log{buf, cap, 0};
+    buf[0] = 0;
+    LaunchLog* const outer = t_launch_log;
+    t_launch_log = &log;
+    int rc;
+    if (which == FASN_PLAN_FWD) rc = fasn_fwd(&args->fwd, nullptr);
+    else if (which == FASN_PLAN_BWD) rc = fasn_bwd(args, nullptr);
+    else rc = fasn_fwd_ws(&args->fwd, reinterpret_cast<void*>(uintptr_t(256)), ~size_t(0), nullptr);   // (nothing is launched: any aligned address stands for the workspace)
+    t_launch_log = outer;
+    if (rc) return rc;
+    return log.len > cap ? FASN_EINVAL : (int)log.len;
 }
 
 }  // extern "C"

@@ -15,14 +15,14 @@ static int launch_ws256(BwdParams p, hipStream_t s) {
     {
         constexpr int RPB = 256 / (D / 8);
         const int64_t rows = (int64_t)nbh * p.f.Sq;
-        hipLaunchKernelGGL((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
+        FASN_LAUNCH((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
     }
     {
         constexpr int smem = bwd_dq_ws256_smem_bytes();
         p.nblk = (p.f.Sq + 127) / 128;
         constexpr auto kern = &fasn_bwd_dq_ws256_kernel<Tag, MODE>;
         ensure_smem<kern>(smem);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+        FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
     }
     {
         constexpr int smem = bwd_ws256_smem_bytes();
@@ -30,11 +30,11 @@ static int launch_ws256(BwdParams p, hipStream_t s) {
         if (MODE == MODE_CAUSAL || (MODE == MODE_KEYPAD && p.f.causal)) {
             constexpr auto kern = &fasn_bwd_dkdv_ws256_kernel<Tag, MODE_CAUSAL>;
             ensure_smem<kern>(smem);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+            FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
         } else {
             constexpr auto kern = &fasn_bwd_dkdv_ws256_kernel<Tag, MODE_PLAIN>;
             ensure_smem<kern>(smem);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+            FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
         }
     }
     return launch_rc();

@@ -11,7 +11,7 @@ static int launch_k(const DbiasParams& dp, hipStream_t s) {
     ensure_smem<kern>(smem);
     const long tiles = (long)dp.Bb * dp.Hb * dp.nqb * dp.nkb;
     const long grid = tiles < 1024 ? tiles : 1024;   // persistent: one workgroup per CU is resident (LDS), four waves of tiles each
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, dp);
+    FASN_LAUNCH(kern, dim3((unsigned)grid), dim3(256), smem, s, dp);
     return launch_rc();
 }
 // the two-role pipeline (fasn_bwd_dbias_ws.h): one persistent workgroup of 8 waves per CU, its own lean parameter block
@@ -20,12 +20,15 @@ static int launch_ws(const DbiasParams& dp, hipStream_t s) {
     constexpr int smem = dbias_ws_smem_bytes<D>();
     constexpr auto kern = &fasn_bwd_dbias_ws_kernel<Tag, D>;
     ensure_smem<kern>(smem);
-    static std::atomic<int> cus{0};
-    int n = cus.load(std::memory_order_relaxed);
+    // CUs of the CURRENT device (the stream's device by the ABI contract), cached per device ordinal like ensure_smem's attribute bit:
+    // a partitioned part (CPX: 32 CUs per device) next to a whole one must not inherit its grid
+    static std::atomic<int> cus[64];
+    int dev = 0, n = 0;
+    if (t_launch_log != nullptr || hipGetDevice(&dev) != hipSuccess) dev = -1;   // (recording a launch plan: no HIP call, a whole MI355X assumed)
+    if (dev >= 0 && dev < 64) n = cus[dev].load(std::memory_order_relaxed);
     if (n == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus.store(n, std::memory_order_relaxed);
+        if (dev < 0 || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        if (dev >= 0 && dev < 64) cus[dev].store(n, std::memory_order_relaxed);
     }
     const BwdParams& b = dp.b;
     const FwdParams& f = b.f;
@@ -40,8 +43,9 @@ static int launch_ws(const DbiasParams& dp, hipStream_t s) {
     const long tiles = (long)dp.Bb * dp.Hb * dp.nqb * dp.nkb;
     const int grid = (int)(tiles < n ? tiles : n);
     w.dk = grid % dp.nkb, w.dq = (grid / dp.nkb) % dp.nqb, w.dh = (grid / (dp.nkb * dp.nqb)) % dp.Hb, w.db = grid / (dp.nkb * dp.nqb * dp.Hb);
-    w.xorder = (grid == 256 && dp.Hb % 8 == 0 && dp.nkb % 8 == 0 && dp.nqb % 4 == 0 && !(FASN_BWD_VARIANT & 4096)) ? 1 : 0;   // (developer library: bit 12 = plain tile order)
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, s, w);
+    // XCD-local tile order: written for 8 XCDs of 32 CUs with workgroup i on XCD i % 8 (a whole MI355X); any other device keeps the plain order
+    w.xorder = (n == 256 && grid == 256 && dp.Hb % 8 == 0 && dp.nkb % 8 == 0 && dp.nqb % 4 == 0 && !(FASN_BWD_VARIANT & 4096)) ? 1 : 0;   // (developer library: bit 12 = plain tile order)
+    FASN_LAUNCH(kern, dim3((unsigned)grid), dim3(512), smem, s, w);
     return launch_rc();
 }
 template <typename Tag, int D>

@@ -63,13 +63,13 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     // tiles (the in-order dispatcher makes a round as long as its longest workgroup: 19 % idle CUs here). The second element runs through
     // a second inlined copy of the body - no loop-carried state (a pass loop cost 18 spilled registers in round 3).
     constexpr bool KPAIR = KP && VBIAS && !DROP;
-    int bh0, qi0, bh2 = -1;
+    int bh0, qi0, bh2 = -1, kp_lead = 0;
     if (VBIAS && p.batch_inner && (p.H & 7) == 0) {   // the B workgroups that read the same bias rows run together on one XCD
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         int bb = j % p.B, rest = j / p.B;
         if constexpr (KPAIR) {
             int b0 = -1, b1 = -1;
-            if (kpair_plan(p, smem, tid, j % ((p.B + 1) / 2), b0, b1)) {
+            if (kpair_plan(p, smem, tid, j % ((p.B + 1) / 2), b0, b1, kp_lead)) {
                 const int np = (p.B + 1) / 2;
                 if (j >= (p.H >> 3) * bp.nblk * np) return;
                 rest = j / np;
@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     } else {
         block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh0, qi0);
     }
-    auto item = [&](const int bh, const int qi) __attribute__((always_inline)) {
+    auto item = [&](const int bh, const int qi, auto SECOND_) __attribute__((always_inline)) {
+    constexpr bool ROT = KPAIR && decltype(SECOND_)::value;   // second element of a length pair: rotated key walk (fasn_fwd_kernel.h, kpair_plan)
     const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
     const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
@@ -183,6 +184,29 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
         for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
         ntiles = __builtin_amdgcn_readfirstlane(last + 1);
     }
+    // second element of a length pair: step t works on tile (t + rot) mod ntiles - the workgroups of a (head, query block) group, which
+    // start their second elements kp_lead steps apart, then ask for the same bias tile at the same time; steps past the end map to a
+    // tile behind the last key (requests out of the descriptors' range: zeros)
+    int rot = 0;
+    if (ROT && p.kprot && ntiles > 0) rot = (ntiles - kp_lead % ntiles) % ntiles;
+    const int nt_all = (p.Sk + KT - 1) / KT;
+    auto phys = [&](int t) {
+        if constexpr (!ROT) return t;
+        else {
+            const int u = t + rot;
+            return t >= ntiles ? nt_all : (u >= ntiles ? u - ntiles : u);
+        }
+    };
+    if (ROT && role == 0 && rot != 0) {   // the prologue requested the images of tiles 0 and 1: replace them (same slots, same count)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bias_request(phys(0), 0);
+        bias_request(phys(1), 1);
+    }
+    if (ROT && rot != 0) {   // and K tile 0
+        k_dma(phys(0), 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (role == 0) {   // Q' = Q * scale*log2e, rounded to the operand type (like the pre-scaled q of core/flash_attn.py:81-83)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -208,7 +232,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     const int vis = causal ? (row + coff) : 0x7fffffff;
     const uint32_t drop_rb = DROP ? drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row) : 0u;
     // wave-uniform classification of (this wave's 32 rows) x (key tile t): identical for the A and the B wave of a row block
-    auto classify = [&](int t, bool& skip, bool& need_mask, uint64_t& kp_bits) {
+    auto classify = [&](int t, bool& skip, bool& need_mask, uint64_t& kp_bits) {   // t: the tile itself (phys(step))
         const int k0 = t * KT;
         skip = qw0 >= p.Sq;
         need_mask = false;
@@ -230,9 +254,10 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     auto pslot = [&](int pb) { return ldsP + pb * PBUF + rbw * 4096 + lane * 16; };
 
     // ---- wave A: key tile t
-    auto tile_a = [&](const int t, auto BUF_, const int par) {
+    auto tile_a = [&](const int step, auto BUF_, const int par) {
         constexpr int buf = decltype(BUF_)::value;
         const char* tK = ldsK + buf * TILEB;
+        const int t = phys(step);   // the tile this step works on
         bool skip, need_mask;
         uint64_t kp_bits;
         classify(t, skip, need_mask, kp_bits);
@@ -248,7 +273,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
                     braw[kb][2 * j + 1] = u32x2{w[2], w[3]};
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before its slot is requested again
-            bias_request(t + 2, par);
+            bias_request(phys(step + 2), par);
         }
         if (skip) return;
         vec8 pf[2][2];
@@ -321,10 +346,11 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     };
 
     // ---- wave B: key tile t (the one wave A finished in the previous iteration)
-    auto tile_b = [&](const int t, auto BUF_, const int par) {
+    auto tile_b = [&](const int step, auto BUF_, const int par) {
         constexpr int buf = decltype(BUF_)::value;
         const char* tK = ldsK + buf * TILEB;
         const char* tV = ldsV + par * TILEB;
+        const int t = phys(step);
         bool skip, need_mask;
         uint64_t kp_bits;
         classify(t, skip, need_mask, kp_bits);
@@ -402,8 +428,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     auto run = [&](auto ROLE_) {
         constexpr int ROLE = decltype(ROLE_)::value;
         auto body = [&](const int t, auto BA_, auto BB_, auto BN_) {
-            if (t + 1 < ntiles) k_dma(t + 1, decltype(BN_)::value);
-            if (t < ntiles) v_dma(t, t & 1);
+            if (t + 1 < ntiles) k_dma(phys(t + 1), decltype(BN_)::value);
+            if (t < ntiles) v_dma(phys(t), t & 1);
             if (ROLE == 0) {
                 if (t < ntiles) tile_a(t, BA_, t & 1);
             } else {
@@ -443,11 +469,11 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
             }
     }
     };   // item
-    item(bh0, qi0);
+    item(bh0, qi0, std::false_type{});
     if constexpr (KPAIR) {
         if (bh2 >= 0) {
             __syncthreads();   // every wave is done with the first element's LDS
-            item(bh2, qi0);
+            item(bh2, qi0, std::true_type{});
         }
     }
 }

@@ -10,20 +10,20 @@ static int launch_bwd_fused(BwdParams p, int mode, hipStream_t s) {
     const int nbh = p.f.B * p.f.H;
     const int64_t rows = (int64_t)nbh * p.f.Sq;
     constexpr int RPB = 256 / (D / 8);
-    hipLaunchKernelGGL((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
+    FASN_LAUNCH((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
     if (hipMemsetAsync(p.dqacc, 0, (size_t)rows * D * sizeof(float), s) != hipSuccess) return -6;
     constexpr int smem = fused_smem_bytes();
     p.nblk = (p.f.Sk + FBN - 1) / FBN;
     if (mode == MODE_CAUSAL) {
         constexpr auto kern = &fasn_bwd_fused_kernel<Tag, MODE_CAUSAL, ABL>;
         ensure_smem<kern>(smem);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+        FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
     } else {
         constexpr auto kern = &fasn_bwd_fused_kernel<Tag, MODE_PLAIN, ABL>;
         ensure_smem<kern>(smem);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+        FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
     }
-    hipLaunchKernelGGL((fasn_bwd_dq_convert_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
+    FASN_LAUNCH((fasn_bwd_dq_convert_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
     return launch_rc();
 }
 

@@ -35,7 +35,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     {   // delta
         constexpr int RPB = 256 / (D / 8);
         const int64_t rows = (int64_t)nbh * p.f.Sq;
-        hipLaunchKernelGGL((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
+        FASN_LAUNCH((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
     }
     bool dq_done = (p.skip & 2) != 0;
     if constexpr (WS != 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
@@ -45,7 +45,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
             p.nblk = (p.f.Sq + 127) / 128;
             constexpr auto kern = &fasn_bwd_dq_ws_kernel<Tag, D, MODE, DROP>;
             ensure_smem<kern>(smem);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+            FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
             dq_done = true;
         }
     }
@@ -57,7 +57,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         ensure_smem<kern>(smem);
         // causal: block r and block nblk-1-r in one workgroup (equal workgroups for the in-order dispatcher, see fasn_fwd_kernel.h)
         p.f.pair = (MODE == MODE_CAUSAL && !DROP && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * OCC_Q)) ? 1 : 0;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
+        FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
         p.f.pair = 0;
     }
     if (p.skip & 1) return launch_rc();
@@ -69,14 +69,14 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
                 if (p.f.kvg > 1) {   // grouped-query attention: one workgroup per K/V head walks the query heads of its group
                     constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE, 1>;
                     ensure_smem<kern>(smem);
-                    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(512), smem, s, p);
+                    FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(512), smem, s, p);
                     return launch_rc();
                 }
             }
             {
                 constexpr auto kern = &fasn_bwd_dkdv_ws_kernel<Tag, D, MODE, 0, DROP>;
                 ensure_smem<kern>(smem);
-                hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
+                FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
             }
             return launch_rc();
         }
@@ -88,12 +88,12 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         if (p.f.kvg > 1) {
             constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 1, DH>;
             ensure_smem<kern>(smem);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg) * DH)), dim3(256), smem, s, p);
+            FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg) * DH)), dim3(256), smem, s, p);
         } else {
             constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 0, DH>;
             ensure_smem<kern>(smem);
             p.f.pair = (MODE == MODE_CAUSAL && !DROP && DH == 1 && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * OCC_K)) ? 1 : 0;
-            hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh * DH)), dim3(256), smem, s, p);
+            FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh * DH)), dim3(256), smem, s, p);
         }
     }
     return launch_rc();

@@ -12,7 +12,7 @@ static int launch_dkdv_pipe(BwdParams p, hipStream_t s) {
     constexpr auto kern = &fasn_bwd_dkdv_pipe_kernel<Tag, MODE, DROP>;
     ensure_smem<kern>(smem);
     p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * 2)) ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
+    FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
     return launch_rc();
 }
 
@@ -25,7 +25,7 @@ static int launch_dq_pipe(BwdParams p, hipStream_t s) {
     constexpr auto kern = &fasn_bwd_dq_pipe_kernel<Tag, MODE, DROP>;
     ensure_smem<kern>(smem);
     p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * 2)) ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
+    FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
     return launch_rc();
 }
 
@@ -48,7 +48,7 @@ static int launch_dkdv_pipe2(BwdParams p, hipStream_t s) {
     constexpr auto kern = &fasn_bwd_dkdv_pipe2_kernel<Tag, MODE, KB>;
     ensure_smem<kern>(smem);
     p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L)) ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
+    FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
     return launch_rc();
 }
 int launch_bwd_dkdv_pipe2_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {

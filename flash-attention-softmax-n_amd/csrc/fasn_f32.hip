@@ -11,7 +11,7 @@ static int fwd_one(FwdParams p, hipStream_t s) {
     p.nqblk = (p.Sq + 127) / 128;
     constexpr auto kern = &fasn_f32_fwd_kernel<D, MODE>;
     ensure_smem<kern>(smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
+    FASN_LAUNCH(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(256), smem, s, p);
     return launch_rc();
 }
 
@@ -21,14 +21,14 @@ static int bwd_one(BwdParams p, hipStream_t s) {
     {
         constexpr int RPB = 256 / (D / 4);
         const int64_t rows = (int64_t)nbh * p.f.Sq;
-        hipLaunchKernelGGL((fasn_f32_delta_kernel<D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
+        FASN_LAUNCH((fasn_f32_delta_kernel<D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
     }
     {
         constexpr int smem = 4 * 64 * D * 4;
         p.nblk = (p.f.Sq + 127) / 128;
         constexpr auto kern = &fasn_f32_dq_kernel<D, MODE>;
         ensure_smem<kern>(smem);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
+        FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * nbh)), dim3(256), smem, s, p);
     }
     {
         constexpr int smem = 4 * 64 * D * 4 + 4 * 64 * 4;
@@ -36,7 +36,7 @@ static int bwd_one(BwdParams p, hipStream_t s) {
         constexpr auto kern = &fasn_f32_dkdv_kernel<D, MODE>;
         ensure_smem<kern>(smem);
         // one workgroup per K/V head: the kernel sums the query heads of a GQA group itself
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(256), smem, s, p);
+        FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(256), smem, s, p);
     }
     return launch_rc();
 }

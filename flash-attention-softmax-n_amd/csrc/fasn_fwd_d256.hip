@@ -14,7 +14,7 @@ static int launch_ws256(FwdParams p, hipStream_t s) {
     p.nqblk = (p.Sq + 127) / 128;
     constexpr auto kern = &fasn_fwd_ws256_kernel<Tag, MODE>;
     ensure_smem<kern>(smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(512), smem, s, p);
+    FASN_LAUNCH(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(512), smem, s, p);
     return launch_rc();
 }
 template <typename Tag>

@@ -33,6 +33,8 @@ static int dev_variant(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     switch (l.variant) {
         // ---- production tuning points
         case 100: return launch_fwd_mode<Tag, 64, 2, 2>(p, l.mode, s);
+        case 90: return launch_fwd_cfg<Tag, 64, 2, 2, 4, 2, 2>(p, l.mode, s);   // the plain kernel's tuning point for any mode (causal: paired blocks by the shipped rule)
+        case 91: return launch_fwd_cfg<Tag, 64, 1, 3, 4, 2, 2>(p, l.mode, s);   // the causal kernel's tuning point for any mode
         case 1: return launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);
         // ---- alternatives kept for A/B measurements (tools/fasn_harness bench ... <variant>)
         case 2: return launch_fwd_mode<Tag, 64, 2, 1>(p, l.mode, s);

@@ -32,6 +32,9 @@
 #ifndef FASN_FWD_UNR2
 #define FASN_FWD_UNR2 1
 #endif
+#ifndef FASN_PIPESEED
+#define FASN_PIPESEED 1
+#endif
 namespace fasn {
 
 // MODE_GENERAL: mask and/or bias through 4-key vector (buffer) loads - needs key stride 1 and aligned rows (bias_vec /
@@ -79,6 +82,7 @@ struct FwdParams {
     int keypad_fallback;   // MODE_KEYPAD launches: the general mode (vector or element-load) the same mask would otherwise take
     int nsplit, tps;
     int pair;       // causal (MODE_CAUSAL kernels): one workgroup takes query block r AND block nqblk-1-r of its head, one after the other
+    int kprot;      // length-paired batch elements: rotate the key walk of the second element (kpair_plan's `lead`); 0 = developer A/B
     float* part_o;   // [B*H][nsplit][Sq][D]
     float* part_ml;  // [B*H][nsplit][Sq][2]
 #ifdef FASN_DEV_VARIANTS
@@ -139,22 +143,35 @@ FASN_DEV void kp_build_words(uint64_t* words, const uint8_t* mrow, int Sk, int n
 // batch is not ragged enough to pay for it (mean length >= 0.85 of the longest). `scratch`: B ints of LDS nobody uses yet; barriers inside, so the whole
 // workgroup calls it. Uniform result.
 constexpr int kPairMaxBatch = 64, kPairMaxBytes = 64 * 1024;
-FASN_DEV bool kpair_plan(const FwdParams& p, char* scratch, int tid, int slot, int& b0, int& b1) {
+// `lead` (tiles): how many tile steps BEFORE the workgroup of the longest element this workgroup finishes its first element - the second
+// passes of a (head, query block) group then start `lead` steps apart. A workgroup that rotates the key walk of its second element by
+// that many tiles (walk tile (t - lead) mod n instead of t: online softmax and the dQ sum do not care about the order) meets the other
+// workgroups of its group at the same bias tile at the same time, and the tile comes out of the L2 instead of being fetched per workgroup.
+FASN_DEV bool kpair_plan(const FwdParams& p, char* scratch, int tid, int slot, int& b0, int& b1, int& lead) {
+    lead = 0;
     if (p.mask == nullptr || p.ms[1] != 0 || p.B < 2 || p.B > kPairMaxBatch || (int64_t)p.B * p.Sk > kPairMaxBytes || (p.Sk & 15) != 0 ||
         (p.ms[0] & 15) != 0 || (reinterpret_cast<uintptr_t>(p.mask) & 15) != 0 || p.pair == 2)   // (pair 2 / 3: developer override)
         return false;
     int* const len = reinterpret_cast<int*>(scratch);
     const int nthreads = (int)blockDim.x;
+    const int lane = tid & 63;
     for (int i = tid; i < p.B; i += nthreads) len[i] = 0;
     __syncthreads();
     const int cpr = p.Sk >> 4;   // 16-byte chunks per mask row
-    for (int c = tid; c < p.B * cpr; c += nthreads) {
-        const int bb = c / cpr, k16 = c - bb * cpr;
-        const u32x4 w = *reinterpret_cast<const u32x4*>(p.mask + (int64_t)bb * p.ms[0] + 16 * k16);
-        if ((w[0] | w[1] | w[2] | w[3]) != 0u) atomicMax(&len[bb], k16 + 1);
+    // one batch element at a time: a thread keeps the last non-zero chunk it saw, the wave folds its 64 candidates with shuffles and ONE lane
+    // posts the result (round 4 posted from every lane: 64 LDS atomics on one address per instruction = all of SQ_LDS_BANK_CONFLICT of the
+    // config-4 launches, 1550 cycles per workgroup)
+    for (int bb = 0; bb < p.B; ++bb) {
+        int mine = 0;
+        for (int k16 = tid; k16 < cpr; k16 += nthreads) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(p.mask + (int64_t)bb * p.ms[0] + 16 * k16);
+            if ((w[0] | w[1] | w[2] | w[3]) != 0u) mine = k16 + 1;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine = max(mine, __shfl_xor(mine, o));
+        if (lane == 0 && mine > 0) atomicMax(&len[bb], mine);
     }
     __syncthreads();
-    const int lane = tid & 63;
     const int mine = lane < p.B ? len[lane] : -1;
     __syncthreads();   // `len` has been read: the scratch may be reused by the caller
     int rank = 0, lmax = 0, lsum = 0;
@@ -170,6 +187,7 @@ FASN_DEV bool kpair_plan(const FwdParams& p, char* scratch, int tid, int slot, i
     const uint64_t m0 = __ballot(lane < p.B && rank == slot), m1 = __ballot(lane < p.B && rank == p.B - 1 - slot);
     b0 = __builtin_ctzll(m0);
     b1 = __builtin_ctzll(m1);
+    lead = (lmax + 3) / 4 - (__builtin_amdgcn_readlane(mine, b0) + 3) / 4;
     return true;
 }
 
@@ -230,6 +248,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     constexpr bool PAIRABLE = MODE == MODE_CAUSAL && !SPLIT && VH == 1 && !DROP;
     constexpr bool KPAIR = KP && VBIAS && !SPLIT && VH == 1 && !DROP;   // length-paired batch elements (see below)
     int bh2 = -1;   // KPAIR: the (b,h) of the second pass
+    int kp_lead = 0;   // KPAIR: tile steps by which this workgroup starts its second pass before the group's last one (kpair_plan)
     if (SPLIT) {
         int blk;
         block_to_work(wgid, p.B * p.H, p.nqblk * p.nsplit, bh, blk);
@@ -247,7 +266,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             // workgroups of the launch cost about the same. The other half of the workgroup ids leaves at once (last ids = whole
             // rounds). Batches that are not ragged enough keep the plain schedule (one bias fetch serves B workgroups instead of two).
             int b0 = -1, b1 = -1;
-            if (kpair_plan(p, smem, tid, j % ((p.B + 1) / 2), b0, b1)) {
+            if (kpair_plan(p, smem, tid, j % ((p.B + 1) / 2), b0, b1, kp_lead)) {
                 const int np = (p.B + 1) / 2;
                 if (j >= (p.H >> 3) * p.nqblk * np) return;
                 rest = j / np;
@@ -308,6 +327,19 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     }
     const int t_begin = SPLIT ? split * p.tps : 0;   // tps is a multiple of 6: t & 1 and t % 3 select the LDS buffer as if t started at 0
     if (SPLIT) ntiles = min(ntiles, t_begin + p.tps);
+    // KPAIR, second pass: step t works on tile (t + rot) mod ntiles, so that the workgroups of a (head, query block) group, which enter their
+    // second passes `lead` steps apart, request the same bias tile at the same time (one fetch through the L2 instead of one per workgroup).
+    // Steps past the end map to a tile behind the last key: their requests are out of range for the descriptors and fill zeros.
+    int rot = 0;
+    if (KPAIR && pass && p.kprot && ntiles > 0) rot = (ntiles - kp_lead % ntiles) % ntiles;
+    const int nt_all = (p.Sk + KT - 1) / KT;
+    auto phys = [&](int t) {
+        if constexpr (!KPAIR) return t;
+        else {
+            const int u = t + rot;
+            return t >= ntiles ? nt_all : (u >= ntiles ? u - ntiles : u);
+        }
+    };
 
     // ---- Q fragments (B operand: col = q = lane&31, k = 8*hi..8*hi+7 of each 16-wide step)
     vec8 qf[QB][KS];
@@ -478,9 +510,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const float binv = bias_fold ? (SEED ? kLog2e : kLog2e / p.c) : 0.f;   // SEED: Q is pre-scaled, S' = bias*log2e - m + q'.k
     if (RING == 2) {
         if (ntiles > t_begin) {
-            if (VEC) gen_dma(t_begin);
-            stage_direct(t_begin, 0);
-            stage_direct(t_begin + 1, 1);
+            if (VEC) gen_dma(phys(t_begin));
+            stage_direct(phys(t_begin), 0);
+            stage_direct(phys(t_begin + 1), 1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile 0 (and Q) landed; tile 1 in flight
         }
     } else if (ntiles > t_begin) {
@@ -524,13 +556,31 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 
     // this tile's visibility word is read (uniform address) while the tile before is computed
     uint64_t kp_next = 0;
-    if (KP && t_begin < ntiles) kp_next = ldsKP[t_begin];
+    if (KP && t_begin < ntiles) kp_next = ldsKP[phys(t_begin)];
 
     // Direct-to-LDS vector kernels (LATE): the image of a tile is moved LDS -> registers at the END of the tile before, between
     // the wait that precedes the barrier and the barrier itself, and the image after it is requested there: the LDS latency
     // and the request instructions then sit where the wave waits for its neighbours anyway instead of in front of the tile's
     // first MFMA (both waves of a SIMD belong to one workgroup and run in phase, so nothing else covered them there).
     constexpr bool LATE = VEC && RING == 2;
+    // PIPESEED (round 5; bias + key-padding kernel): the start values of tile t+1 (bias * log2e - m, one fma and one 16-bit -> fp32
+    // unpack per score) are built BESIDE the PV MFMAs of tile t instead of at the top of tile t+1, where they stood right behind the
+    // barrier with both waves of a SIMD doing VALU work at once and the matrix pipe idle (about a quarter of the tile).
+    // They wait in the QK^T accumulator tuple of the next tile (32 registers per row block, 16 more than the raw image they replace).
+    constexpr bool PIPESEED = LATE && MODE == MODE_BIAS_KEYPAD && !DROP && QB == 1 && SEED && FASN_PIPESEED;
+    f32x16 seed_n[PIPESEED ? QB : 1][2];
+    auto build_seeds = [&](f32x16 (&dst)[PIPESEED ? QB : 1][2], const u32x2 (&br)[QB][2][4], auto KB_) {   // start values of key block KB_ of the NEXT tile from its image
+        constexpr int kb = decltype(KB_)::value;
+#pragma unroll
+        for (int qb = 0; qb < (PIPESEED ? QB : 1); ++qb) {
+            const float mneg = (m_run[qb] != -INFINITY) ? -m_run[qb] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t w = br[qb][kb][r >> 2][(r & 3) >> 1];
+                dst[qb][kb][r] = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), kLog2e, mneg);
+            }
+        }
+    };
     uint32_t mraw_c[QB][2][4];
     u32x2 braw_c[QB][2][4];
     auto image_to_regs = [&](uint32_t (&mr)[QB][2][4], u32x2 (&br)[QB][2][4]) {
@@ -556,7 +606,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     if (LATE && ntiles > t_begin) {   // (the prologue's wait and barrier above published the first image)
         image_to_regs(mraw_c, braw_c);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        gen_dma(t_begin + 1);
+        gen_dma(phys(t_begin + 1));
+        if constexpr (PIPESEED) {
+            build_seeds(seed_n, braw_c, std::integral_constant<int, 0>{});
+            build_seeds(seed_n, braw_c, std::integral_constant<int, 1>{});
+        }
     }
 
     // one K/V tile; LSET = register set that receives the prefetch issued here, SSET = set written to LDS at the end
@@ -569,14 +623,14 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         // tripled loop body, instruction cache)
         const int buf = (UNR3 || UNR2) ? decltype(LSET)::value : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1)));
         const int buf2 = UNR3 ? (decltype(LSET)::value + 2) % 3 : (t + 2) % 3;   // RING 2: buffer of the tile requested now
-        const int k0 = t * KT;
-        if (RING == 2 && !VEC) stage_direct(t + 2, buf2);   // past-the-end tiles are out of range for the descriptor
+        const int k0 = phys(t) * KT;
+        if (RING == 2 && !VEC) stage_direct(phys(t + 2), buf2);   // past-the-end tiles are out of range for the descriptor
         else if (!VEC && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
 
         uint64_t kp_bits = ~0ull;
         if (KP) {   // (the builtin returns a signed int)
             kp_bits = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kp_next >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)kp_next);
-            kp_next = ldsKP[min(t + 1, ntiles - 1)];
+            kp_next = ldsKP[phys(min(t + 1, ntiles - 1))];
         }
         // wave-uniform tile classification
         bool skip = false;       // no visible element for this wave
@@ -595,8 +649,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         uint32_t mraw[QB][2][4];
         u32x2 braw[QB][2][4];
         if (SLOW) need_mask = true;
-        if (LATE) {   // the image is already in registers (end of the previous tile); only the requests of this tile remain
-            stage_direct(t + 2, buf2);
+        if (PIPESEED) {   // the start values of this tile were built beside the PV MFMAs of the tile before
+            stage_direct(phys(t + 2), buf2);
+        } else if (LATE) {   // the image is already in registers (end of the previous tile); only the requests of this tile remain
+            stage_direct(phys(t + 2), buf2);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -611,8 +667,20 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             image_to_regs(mraw, braw);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before the next one is requested
-            gen_dma(t + 1);                                        // past-the-end tiles are out of range: zeros
+            gen_dma(phys(t + 1));                                  // past-the-end tiles are out of range: zeros
             stage_load(t + 1 + RING, LSET);
+        }
+        // PIPESEED: tile t+1 (K / V and image) has landed, tile t+2 stays in flight; the image goes to registers and its slot is requested again
+        auto next_image = [&]() {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+            image_to_regs(mraw_c, braw_c);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before its slot is requested again
+            gen_dma(phys(t + 2));
+        };
+        if (PIPESEED && skip) {   // (a tile this wave does not compute: the next tile's start values are still due)
+            next_image();
+            build_seeds(seed_n, braw_c, std::integral_constant<int, 0>{});
+            build_seeds(seed_n, braw_c, std::integral_constant<int, 1>{});
         }
         if (!skip) {
             const char* tK = ldsK + buf * TILEB;
@@ -642,6 +710,12 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             if (VEC) {
                 // S' starts from the additive term: bias*log2e/c where the mask byte is set, -inf where it is clear
                 // (S' = add + q.k, y = c*S'): from here on the tile is handled exactly like a plain one
+                if constexpr (PIPESEED) {
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) sacc[qb][kb] = seed_n[qb][kb];
+                } else
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     const float mneg = (SEED && m_run[qb] != -INFINITY) ? -m_run[qb] : 0.f;
@@ -876,8 +950,13 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             }
 
             // ---- O^T += V^T P^T
+            if constexpr (PIPESEED) next_image();
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                if constexpr (PIPESEED) {   // the start values of key block kb of tile t+1, independent of everything around them: VALU work for the MFMA shadow
+                    if (kb == 0) build_seeds(seed_n, braw_c, std::integral_constant<int, 0>{});
+                    else build_seeds(seed_n, braw_c, std::integral_constant<int, 1>{});
+                }
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -895,14 +974,16 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
                     }
+                if constexpr (PIPESEED) __builtin_amdgcn_sched_barrier(0);   // (keeps the second key block's V fragments from being hoisted over the first one's: 11 spilled registers without it)
+            }
         }
 
         if (RING == 2) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile t+1 (and its image) is in LDS, tile t+2 still in flight
-            if (LATE) {   // next tile's image -> registers, the one after it requested (ordered by an explicit lgkmcnt wait: a DMA landing before a queued read would be silent corruption)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD + (PIPESEED ? 4 * QB : 0)) : "memory");   // tile t+1 (and its image) is in LDS, tile t+2 (PIPESEED: and the image request behind it) still in flight
+            if (LATE && !PIPESEED) {   // next tile's image -> registers, the one after it requested (ordered by an explicit lgkmcnt wait: a DMA landing before a queued read would be silent corruption)
                 image_to_regs(mraw_c, braw_c);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before its slot is requested again
-                gen_dma(t + 2);
+                gen_dma(phys(t + 2));
             }
             __syncthreads();
         } else {

@@ -15,9 +15,9 @@ int launch_splitk_one(FwdParams p, hipStream_t s) {
     p.nqblk = (p.Sq + BM - 1) / BM;
     constexpr auto kern = &fasn_fwd_kernel<Tag, D, 1, MODE, OCC, 4, 0, 0, RING, 1>;
     ensure_smem<kern>(smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.nsplit * p.B * p.H)), dim3(256), smem, s, p);
+    FASN_LAUNCH(kern, dim3((unsigned)(p.nqblk * p.nsplit * p.B * p.H)), dim3(256), smem, s, p);
     const int64_t nthr = (int64_t)p.B * p.H * p.Sq * (D / 4);
-    hipLaunchKernelGGL((fasn_fwd_combine_kernel<Tag, D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p);
+    FASN_LAUNCH((fasn_fwd_combine_kernel<Tag, D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p);
     return launch_rc();
 }
 template <typename Tag, int D>

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
     const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2;
 
     int nu = (p.Sk + KU - 1) / KU;   // key blocks this workgroup walks
+    const int nu_all = nu;           // the first unit behind the last key: a request for it is out of the descriptors' range (zero fill, no traffic)
     if (causal) {
         const int kmax = min(q0 + BM, p.Sq) - 1 + coff;
         nu = min(nu, kmax < 0 ? 0 : kmax / KU + 1);
@@ -82,11 +83,11 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
     const uint32_t ldsK_w = lds_addr(ldsK) + wave * 1024, ldsV_w = lds_addr(ldsV) + wave * 1024;
     auto k_dma = [&](int u, int slot) {   // (units past the end of K read back as zeros; 2 requests)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) lds_dma16(krw, __builtin_amdgcn_readfirstlane(ldsK_w + slot * W256_UNIT + i * 8192), voffK[i], u * KU * (int)p.ks[2] * 2);
+        for (int i = 0; i < 2; ++i) lds_dma16(krw, __builtin_amdgcn_readfirstlane(ldsK_w + slot * W256_UNIT + i * 8192), voffK[i], (uint32_t)u * (uint32_t)(KU * (int)p.ks[2] * 2));
     };
     auto v_dma = [&](int u, int slot) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) lds_dma16(vrw, __builtin_amdgcn_readfirstlane(ldsV_w + slot * W256_UNIT + i * 8192), voffV[i], u * KU * (int)p.vs[2] * 2);
+        for (int i = 0; i < 2; ++i) lds_dma16(vrw, __builtin_amdgcn_readfirstlane(ldsV_w + slot * W256_UNIT + i * 8192), voffV[i], (uint32_t)u * (uint32_t)(KU * (int)p.vs[2] * 2));
     };
 
     // ---- prologue: the first K / V units (iteration u requests K unit u + 3 and V unit u + 2; before the loop: K 0..2, V 0..1)
@@ -207,8 +208,10 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
     // u - 2, so the wait that ends an iteration leaves the requests of this iteration and the previous one in flight: 2 x (2 + 2) per wave.
     // Each role runs its own copy of the loop (same trip count, same barriers): Q' lives in A's branch only, O^T in B's.
     auto requests = [&](int u) {
-        k_dma(u + 3 < nu ? u + 3 : nu + 8, (u + 3) & 3);   // (past the end: zero fill, keeps the request counts uniform)
-        v_dma(u + 2 < nu ? u + 2 : nu + 8, (u + 2) & 3);
+        // (past the end of the WALK - which a causal bound or a key-padding trim may have shortened - ask for the unit behind the last KEY:
+        // out of range, zero fill, no traffic; the request counts stay uniform)
+        k_dma(u + 3 < nu ? u + 3 : nu_all, (u + 3) & 3);
+        v_dma(u + 2 < nu ? u + 2 : nu_all, (u + 2) & 3);
     };
     auto close = [&]() {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <typeinfo>
 #include "fasn_fwd_kernel.h"
 
 namespace fasn {
@@ -25,9 +26,29 @@ int launch_fwd_splitk(const FwdParams& p, const FwdLaunch& l, hipStream_t s);   
 // A kernel that needs more than 48 KiB of dynamic LDS must be told so once per (kernel, device). The attribute is per
 // device, so the "done" state is one bit per device ordinal of THIS kernel (the template parameter is the kernel itself:
 // one static per instantiation); after the first launch on a device the launch path only reads an atomic.
+// Launch recorder (fasn_launch_plan, include/fasn.h): while the calling thread has a log installed, every launch site of the library
+// (FASN_LAUNCH) writes "kernel<template arguments> grid=G block=T lds=L" into it INSTEAD of launching, and no HIP call is made - the
+// host side of fasn_fwd / fasn_bwd then runs to its end exactly as for a real call, so the record is the launch table itself, not a
+// description of it (bench.py prints it as roofline.kernels; tests/test_spill_gate.py looks the names up in the code objects).
+struct LaunchLog {
+    char* buf;
+    size_t cap, len;
+};
+extern thread_local LaunchLog* t_launch_log;
+void log_launch(const char* pretty, unsigned grid, unsigned block, int smem);
+template <auto Kern>
+struct KernelTag {};
+template <auto Kern>
+const char* kernel_pretty_name() { return typeid(KernelTag<Kern>).name(); }   // mangled "fasn::KernelTag<&(void fasn::kernel<arguments>(Params))>": log_launch demangles it (__PRETTY_FUNCTION__ drops a function template's arguments)
+#define FASN_LAUNCH(kern, grid, block, smem, stream, ...)                                                                    \
+    do {                                                                                                                       \
+        if (::fasn::t_launch_log != nullptr) ::fasn::log_launch(::fasn::kernel_pretty_name<(kern)>(), (grid).x, (block).x, (int)(smem)); \
+        else hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__);                                                \
+    } while (0)
+
 template <auto Kern>
 inline void ensure_smem(int smem) {
-    if (smem <= 48 * 1024) return;
+    if (smem <= 48 * 1024 || t_launch_log != nullptr) return;
     static std::atomic<uint64_t> done{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
@@ -36,7 +57,7 @@ inline void ensure_smem(int smem) {
     (void)hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (dev < 64) done.fetch_or(bit, std::memory_order_relaxed);
 }
-inline int launch_rc() { return hipGetLastError() == hipSuccess ? 0 : -6; }
+inline int launch_rc() { return (t_launch_log != nullptr || hipGetLastError() == hipSuccess) ? 0 : -6; }
 
 constexpr bool mode_is_vec(int MODE) { return mode_is_vector(MODE); }
 constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB) {
@@ -46,6 +67,7 @@ constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB) {
 // one instantiation of the forward kernel: NW waves x QB 32-row blocks per wave, staging scheme RING, accumulator seeding SEED
 constexpr int kPairRounds = 2;   // (measured: C3, 5.3 rounds of single blocks, 0.350 -> 0.335 ms paired; C5, 43 rounds, 2.45 -> 2.39; (4,32,8192,128) 2.19 -> 2.14)
 #ifdef FASN_DEV_VARIANTS
+extern int g_kprot;       // developer library: 0 = no rotated second pass of a length pair (A/B)
 extern int g_pair_mode;   // developer library: -1 = shipped rule, 0 = never pair, 1 = always pair (tools/fasn_harness, env FASN_PAIR)
 inline bool pair_wanted(long blocks, long slots) { return g_pair_mode < 0 ? blocks >= kPairRounds * slots : g_pair_mode != 0; }
 #else
@@ -70,7 +92,7 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
     // length-paired batch elements (kpair_plan): developer override through the same switch - 2 = never, 3 = whatever the lengths
     if (mode_has_keypad(MODE) && mode_has_vbias(MODE) && g_pair_mode >= 0) p.pair = g_pair_mode ? 3 : 2;
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * p.B * p.H * VH)), dim3(NW * 64), smem, s, p);
+    FASN_LAUNCH(kern, dim3((unsigned)(blocks * p.B * p.H * VH)), dim3(NW * 64), smem, s, p);
     return launch_rc();
 }
 
@@ -134,7 +156,7 @@ int launch_fwd_ring_one(FwdParams p, hipStream_t s) {
     p.nqblk = (p.Sq + BM - 1) / BM;
     constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, PRIO, 0, RING, 0, SEED>;
     ensure_smem<kern>(smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(NW * 64), smem, s, p);
+    FASN_LAUNCH(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(NW * 64), smem, s, p);
     return launch_rc();
 }
 template <typename Tag, int D, int QB, int OCC, int RING = 1, int PRIO = 0, int SEED = 0>

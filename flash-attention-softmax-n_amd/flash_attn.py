@@ -402,6 +402,24 @@ def _prepare(query, key, value, n, scale, dropout_p, mask, bias):
     return q, k, v, mask, bias, n, scale, dropout_p, dpad, Ev, bias_small
 
 
+def _regroup_decode(q, k, mask, bias, dropout_p):
+    """Grouped-query decode (one query position, fewer K/V heads than query heads, no dropout): the G query heads of a group become G
+    query ROWS of one problem per K/V head, so each K/V head is streamed once instead of G times. With one query position a row sees
+    every key, so causal needs no flag, and a [B,H,1,S] mask / bias is a per-row mask / bias of the regrouped problem. All of it is
+    views. Returns (q, mask, bias) of the regrouped problem, or None when the call keeps the per-head launch."""
+    B, H, L, dpad = q.shape
+    Hkv, S = k.shape[1], k.shape[2]
+    if not (L == 1 and Hkv != H and dropout_p == 0.0):
+        return None
+    G = H // Hkv
+    try:
+        mask_g = None if mask is None else mask.view(B, Hkv, G, S)
+        bias_g = None if bias is None else bias.expand(B, H, L, S).view(B, Hkv, G, S)
+    except RuntimeError:      # strides that cannot be regrouped without a copy: keep the per-head launch
+        return None
+    return q.view(B, Hkv, G, dpad), mask_g, bias_g
+
+
 def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) -> Tensor:
     q, k, v, mask, bias, n, scale, dropout_p, dpad, Ev, bias_small = _prepare(query, key, value, n, scale, dropout_p, mask, bias)
     B, H, L, _ = q.shape
@@ -410,21 +428,12 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
     # (seed, offset, b, h, row, key) - dropout.py is the host mirror
     rng = _next_rng_state(query.device) if dropout_p > 0.0 else None
     _TLS.last_rng_state = rng   # per thread: what last_dropout_state() / last_rng_state() report
-    Hkv = k.shape[1]
-    if L == 1 and Hkv != H and dropout_p == 0.0:
-        # grouped-query decode: the G query heads of a group become G query ROWS of one problem per K/V head, so each K/V head
-        # is streamed once instead of G times. With one query position a row sees every key, so causal needs no flag, and a
-        # [B,H,1,S] mask / bias is a per-row mask / bias of the regrouped problem. All of it is views.
-        G = H // Hkv
-        try:
-            mask_g = None if mask is None else mask.view(B, Hkv, G, S)
-            bias_g = None if bias is None else bias.expand(B, H, L, S).view(B, Hkv, G, S)
-        except RuntimeError:      # strides that cannot be regrouped without a copy: keep the per-head launch
-            mask_g = bias_g = False
-        if mask_g is not False:
-            out = _FlashAttentionSoftmaxN.apply(q.view(B, Hkv, G, dpad), k, v, mask_g, bias_g, n, scale, False, 0.0, None)
-            out = out.view(B, H, 1, dpad)
-            return out if Ev == dpad else out[..., :Ev]
+    rg = _regroup_decode(q, k, mask, bias, dropout_p)
+    if rg is not None:
+        q_g, mask_g, bias_g = rg
+        out = _FlashAttentionSoftmaxN.apply(q_g, k, v, mask_g, bias_g, n, scale, False, 0.0, None)
+        out = out.view(B, H, 1, dpad)
+        return out if Ev == dpad else out[..., :Ev]
     if not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad or (bias is not None and bias.requires_grad))):
         out = _launch_fwd(q, k, v, mask, bias, n, scale, bool(is_causal), dropout_p, rng)[0]   # nothing to differentiate: no autograd node
     else:
@@ -435,13 +444,21 @@ def _attention(query, key, value, n, scale, dropout_p, mask, bias, is_causal) ->
 def kernel_path(query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[Tensor] = None, attn_bias: Optional[Tensor] = None,
                 is_causal: bool = False, dropout_p: float = 0.0, scale: Optional[float] = None) -> str:
     """Name of the kernel family a flash_attention_n call with these arguments is routed to (fasn_fwd_path): "plain", "key-padding",
-    "vector mask/bias", "vector bias + key-padding", "element-load (slow)" or "fp32". Launches nothing."""
+    "vector mask/bias", "vector bias + key-padding", "element-load (slow)" or "fp32". Launches no attention kernel and leaves the
+    per-thread plan cache alone: it runs the argument normalisation of the real call (which may issue its small device ops - a feature
+    pad, the copy of a misaligned operand, a bias cast) and asks fasn_fwd_path about a throw-away argument block built from the
+    canonical tensors, including the regrouping of a grouped-query decode call. fasn_fwd_path looks at layouts and modes only."""
     q, k, v, mask, bias, n, sc, dp, _, _, bias_small = _prepare(query, key, value, 1.0, scale, dropout_p, attn_mask, attn_bias)
     if bias_small:
         bias = bias.expand(q.shape[0], q.shape[1], q.shape[2], k.shape[2])
-    # the plan of exactly the call flash_attention_n would make (same canonical tensors, same cache); fasn_fwd_path looks at layout
-    # and modes only, so the placeholder n = 1 does not matter
-    return _lib.FASN_PATH_NAMES[_plan_for(q, k, v, mask, bias, n, sc, bool(is_causal), dp).path]
+    causal = bool(is_causal)
+    rg = _regroup_decode(q, k, mask, bias, dp)
+    if rg is not None:
+        (q, mask, bias), causal = rg, False
+    a = FwdArgs()
+    _fill_fwd(a, q, k, v, q, q, mask, bias, n, sc, causal, dp)   # (o / lse: any device pointer, the query stands in - nothing is launched)
+    with torch.cuda.device(q.device):
+        return _lib.FASN_PATH_NAMES[_lib.load().fasn_fwd_path(a)]
 
 
 def last_rng_state():

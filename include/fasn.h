@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FASN_ABI_VERSION 4
+#define FASN_ABI_VERSION 5
 
 /* error codes */
 #define FASN_OK 0
@@ -171,6 +171,22 @@ int fasn_rng_advance(uint64_t* state, uint64_t* out, uint64_t increment, fasn_st
 
 size_t fasn_bwd_workspace_bytes(const fasn_bwd_args* args);
 int fasn_bwd(const fasn_bwd_args* args, fasn_stream_t stream);
+
+/*
+ * The launches behind a call (ABI 5; diagnostic like fasn_fwd_path, no counterpart in the reference, whose launch sites are
+ * flash_attention_softmax_n/core/flash_attn_triton.py:278-291,316-335): runs the host side of fasn_fwd (FASN_PLAN_FWD, reads only
+ * args->fwd), fasn_bwd (FASN_PLAN_BWD) or fasn_fwd_ws with the workspace it asks for (FASN_PLAN_FWD_WS) on `args` with every launch
+ * site recording instead of launching, and writes one line per kernel into `buf`:
+ *     "kernel_name<template arguments> grid=G block=T lds=L\n"
+ * (NUL-terminated). No kernel runs, no device memory is touched, no HIP call is made - pointers in `args` only have to be
+ * non-NULL and aligned as for the real call. Returns the number of bytes written (without the NUL), the FASN_E* code the real
+ * call would return, or FASN_EINVAL when `cap` is too small. The names are those of the code objects inside the library, so a
+ * profile (rocprofv3 --kernel-trace) and a register / spill table (llvm-readelf on the bundle) can be matched against them.
+ */
+#define FASN_PLAN_FWD 0
+#define FASN_PLAN_BWD 1
+#define FASN_PLAN_FWD_WS 2
+int fasn_launch_plan(const fasn_bwd_args* args, int32_t which, char* buf, size_t cap);
 
 /*
  * Stand-alone softmax_n over the last dimension of a [rows, cols] matrix (row stride in elements,

@@ -4,10 +4,13 @@ import ctypes
 import os
 import re
 
+import sys
+
 import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def _header_functions():
@@ -38,7 +41,7 @@ def test_library_exports_nothing_but_the_header(pkg):
 
 def test_abi_version_and_strerror(pkg):
     lib = pkg._lib.load()
-    assert lib.fasn_abi_version() == 4
+    assert lib.fasn_abi_version() == 5
     assert lib.fasn_strerror(0) == b"ok"
     for code in range(-8, 0):
         assert len(lib.fasn_strerror(code)) > 5
@@ -93,6 +96,34 @@ def test_argument_validation_codes(pkg):
     b.fwd = _args(pkg)
     assert lib.fasn_bwd(b, None) == -1  # lse / delta missing
     assert lib.fasn_softmax_n_fwd(None, None, 1, 1, 1, 1, 0.0, 0, None) == -1
+
+
+def test_launch_plan_names_the_kernels_of_the_baseline_configs(pkg):
+    """fasn_launch_plan runs the host side of a call with every launch site recording instead of launching (no GPU needed): the
+    BASELINE configs reach the kernel families DESIGN.md names, with the grids their shapes imply"""
+    from baseline_plans import kernels
+    fwd = kernels(pkg, "m0", "fwd")
+    assert len(fwd) == 1 and fwd[0][0].startswith("fasn_fwd_kernel<fasn::bf16_tag, 64, 2, 0,") and fwd[0][1:3] == (8 * 16 * 16, 256)
+    bwd = [k[0].split("<")[0] for k in kernels(pkg, "m0", "bwd")]
+    assert bwd == ["fasn_bwd_delta_kernel", "fasn_bwd_dq_pipe_kernel", "fasn_bwd_dkdv_pipe_kernel"]
+    c3 = kernels(pkg, "c3", "fwd")
+    assert len(c3) == 1 and c3[0][0].startswith("fasn_fwd_kernel<fasn::f16_tag, 64,")
+    c4 = kernels(pkg, "c4", "fwd")
+    assert len(c4) == 1 and c4[0][0].startswith("fasn_fwd_kernel<fasn::bf16_tag, 128, 1, 7,") and c4[0][2] == 512
+    c4b = [k[0].split("<")[0] for k in kernels(pkg, "c4", "bwd")]
+    assert c4b == ["fasn_bwd_delta_kernel", "fasn_bwd_dq_ws_kernel", "fasn_bwd_dkdv_ws_kernel"]
+    assert [k[0].split("<")[0] for k in kernels(pkg, "c1", "fwd")] == ["fasn_f32_fwd_kernel"]
+    # errors come back as the real call's code; a buffer that is too small is an argument error, not a truncated list
+    import ctypes
+    from baseline_plans import bwd_args
+    lib = pkg._lib.load()
+    a = bwd_args(pkg, "m0")
+    small = ctypes.create_string_buffer(16)
+    assert lib.fasn_launch_plan(a, 0, small, 16) == -1
+    a.fwd.D = a.fwd.Dv = 96
+    big = ctypes.create_string_buffer(4096)
+    assert lib.fasn_launch_plan(a, 0, big, 4096) == -3
+    assert lib.fasn_launch_plan(bwd_args(pkg, "m0"), 7, big, 4096) == -1
 
 
 def test_fwd_path_query(pkg):

@@ -1154,10 +1154,19 @@ def test_kernel_path_uses_the_arguments_of_the_real_call(pkg, dev):
     b = torch.randn(4, 100, 96, device=dev, dtype=torch.bfloat16)
     assert kernel_path(q, kv, kv, attn_mask=m, attn_bias=b) == "vector bias + key-padding"
     b90 = torch.randn(4, 100, 90, device=dev, dtype=torch.bfloat16)        # rows 180 bytes apart: not 8-byte vectors
-    with pytest.warns(RuntimeWarning):
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")   # a query warns about nothing and plans nothing (the real call is what warns, once per kind)
         assert kernel_path(q, kv[:, :90], kv[:, :90], attn_bias=b90) == "element-load (slow)"
     assert kernel_path(q, kv[:, :90], kv[:, :90], attn_bias=b[..., :90]) != "element-load (slow)"   # a view with 192-byte rows is fine
     assert kernel_path(q.float(), kv.float(), kv.float()) == "fp32"
+    # grouped-query decode: the query is regrouped exactly as the call does it ([B,H,1,E] -> G rows per K/V head) and nothing is cached
+    from flash_attention_softmax_n_amd import flash_attn as fa
+    before = len(fa._cache())
+    qd = torch.randn(2, 8, 1, 128, device=dev, dtype=torch.bfloat16)
+    kd = torch.randn(2, 2, 512, 128, device=dev, dtype=torch.bfloat16)
+    assert kernel_path(qd, kd, kd, is_causal=True) == "plain"
+    assert len(fa._cache()) == before
 
 
 def test_graph_dropout_state_keeps_its_address_across_reseeding(pkg, dev):

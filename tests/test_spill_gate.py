@@ -15,17 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 LIB = os.path.join(ROOT, "flash-attention-softmax-n_amd", "libfasn.so")
 ALLOW = os.path.join(ROOT, "tests", "golden", "spill_allowance.json")
 
-# (config, pass) -> regular expression over the mangled kernel names it launches (fasn_fwd_path + the launch tables of
-# csrc/fasn_launch.h, fasn_bwd_launch.h, fasn_bwd_d64.hip, fasn_f32.hip)
-BASELINE_KERNELS = {
-    "c1 fp32 (2,2,128,32): forward / delta / dQ / dK,dV": r"fasn_f32_(fwd|dq|dkdv)_kernelILi32ELi0E|fasn_f32_delta_kernelILi32E",
-    "m0 / c2 bf16 D=64 plain forward": r"fasn_fwd_kernelINS_8bf16_tagELi64ELi2ELi0E",
-    "c3 f16 D=64 causal forward": r"fasn_fwd_kernelINS_7f16_tagELi64ELi1ELi1E",
-    "c5 bf16 D=64 causal forward": r"fasn_fwd_kernelINS_8bf16_tagELi64ELi1ELi1E",
-    "c4 bf16 D=128 ALiBi + key padding forward": r"fasn_fwd_kernelINS_8bf16_tagELi128ELi1ELi7E",
-    "m0 / c2 / c3 / c5 backward (delta, pipelined dQ, pipelined dK/dV)": r"fasn_bwd_delta_kernelINS_(8bf16|7f16)_tagELi64E|fasn_bwd_dq_pipe_kernelINS_\w+_tagELi[01]ELi0E|fasn_bwd_dkdv_pipe_kernelINS_\w+_tagELi[01]ELi0E",
-    "c4 backward (delta, two-wave dQ, two-wave dK/dV)": r"fasn_bwd_delta_kernelINS_8bf16_tagELi128E|fasn_bwd_dq_ws_kernelINS_8bf16_tagELi128ELi7ELi0E|fasn_bwd_dkdv_ws_kernelINS_8bf16_tagELi128ELi7ELi0ELi0E",
-}
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 @pytest.fixture(scope="module")
@@ -33,21 +23,39 @@ def table():
     import spill_map
     if not os.path.exists(spill_map.READELF):
         pytest.skip("llvm-readelf not available")
+    if not os.path.exists(LIB):   # *.so is git-ignored: a checkout without a build has nothing to inspect
+        pytest.skip("libfasn.so not built (run __graft_entry__.build() or make -C flash-attention-softmax-n_amd/csrc)")
     t = spill_map.kernel_table(LIB)
     assert len(t) > 300, "could not read the kernel metadata of libfasn.so"
     return t
 
 
-def test_baseline_kernels_do_not_spill(table):
-    rows = []
-    for what, pat in BASELINE_KERNELS.items():
-        hit = {n: v for n, v in table.items() if re.search(pat, n)}
-        assert hit, f"{what}: no kernel matches {pat} (launch tables changed? update BASELINE_KERNELS)"
-        for n, v in sorted(hit.items()):
-            rows.append((what, n, v))
+def _demangled(names):
+    import subprocess
+    import spill_map
+    out = subprocess.run([spill_map.CXXFILT], input="\n".join(names), capture_output=True, text=True, check=True).stdout.splitlines()
+    return dict(zip(out, names))
+
+
+def test_baseline_kernels_do_not_spill(table, pkg):
+    """Which kernels a BASELINE config launches is asked of the library itself (fasn_launch_plan: the launch tables run with recording
+    launch sites, no GPU needed) - not kept as a list of mangled-name patterns that has to follow every change of a template's arity."""
+    from baseline_plans import CONFIGS, kernels
+    by_pretty = _demangled(sorted(table))
+    rows, missing = [], []
+    for cfg in CONFIGS:
+        for which in ("fwd", "bwd"):
+            for name, grid, block, lds in kernels(pkg, cfg, which):
+                hit = [m for d, m in by_pretty.items() if d.startswith("void fasn::" + name + "(")]
+                if len(hit) != 1:
+                    missing.append((cfg, which, name, hit))
+                    continue
+                rows.append((f"{cfg} {which}", name, table[hit[0]]))
+    assert not missing, f"launch-plan names without exactly one code object: {missing}"
+    assert len(rows) >= 4 * len(CONFIGS)   # forward + delta + dQ + dK/dV per config
     print()
     for what, n, v in rows:
-        print(f"{v.get('vgpr', 0):4d} regs  spill {v.get('spill', 0):3d}  scratch {v.get('scratch', 0):4d} B  {what}: {n[9:110]}")
+        print(f"{v.get('vgpr', 0):4d} regs  spill {v.get('spill', 0):3d}  scratch {v.get('scratch', 0):4d} B  {what}: {n[:110]}")
     bad = [(what, n, v["spill"], v.get("scratch", 0)) for what, n, v in rows if v.get("spill", 0) or v.get("scratch", 0)]
     assert not bad, f"kernels reachable from a BASELINE config spill: {bad}"
 

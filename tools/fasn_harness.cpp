@@ -17,6 +17,7 @@
 #include "fasn.h"
 
 extern "C" int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant);
+extern "C" void fasn_dev_set_kprot(int v);       // length pairs: rotated key walk of the second element, 1 shipped / 0 off (env FASN_KPROT)
 extern "C" void fasn_dev_set_pair_mode(int v);   // causal block pairing: -1 shipped rule, 0 off, 1 on (env FASN_PAIR)
 extern "C" void fasn_dev_set_timeline(unsigned long long* buf);   // per-workgroup time stamps of the forward kernels (developer library)
 extern "C" void fasn_dev_set_bwd_variant(int v);   // 1 = one-wave dK/dV kernel where the two-wave kernel is the default
@@ -455,6 +456,8 @@ static int do_test(int variant, bool quick) {
         {"d64 f16 dense mask causal n.5", mk(1, 2, 200, 264, 64, HF, 1, 0.5f, 2, 0), true},
         {"d64 bf16 alibi n.5", mk(2, 4, 256, 256, 64, BF, 0, 0.5f, 0, 1), true},
         {"d128 bf16 alibi+keypad n.5", mk(2, 4, 320, 320, 128, BF, 0, 0.5f, 1, 1), true},
+        {"d128 bf16 alibi+keypad lengths 8/7/6/4 (4,8,1024) n.5 (length pairs, rotated second walk)", mk(4, 8, 1024, 1024, 128, BF, 0, 0.5f, 4, 1), true},
+        {"d128 f16 alibi+keypad lengths (3,8,576x832) n1 (odd batch)", mk(3, 8, 576, 832, 128, HF, 0, 1.f, 4, 1), true},
         {"d64 f16 f32bias+mask causal n1", mk(1, 2, 130, 190, 64, HF, 1, 1.f, 2, 2), true},
         {"d64 bf16 scale.3 n4", mk(1, 1, 1024, 1152, 64, BF, 0, 4.f, 0, 0, 0.3f), true},
         {"d256 bf16 256x320 n.5", mk(1, 2, 256, 320, 256, BF, 0, 0.5f), true},
@@ -631,6 +634,7 @@ int main(int argc, char** argv) {
         return 2;
     }
     if (const char* pm = getenv("FASN_PAIR")) fasn_dev_set_pair_mode(atoi(pm));
+    if (const char* kr = getenv("FASN_KPROT")) fasn_dev_set_kprot(atoi(kr));
     if (const char* bv = getenv("FASN_BWDV")) fasn_dev_set_bwd_variant(atoi(bv));   // backward kernel variant for `test` (bench takes it as an argument)
     std::string cmd = argv[1];
     if (cmd == "probe") return do_probe();

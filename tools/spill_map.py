@@ -14,7 +14,7 @@ import sys
 import tempfile
 
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
-CXXFILT = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+CXXFILT = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt" if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-cxxfilt") else "c++filt"
 
 
 def code_objects(path):
