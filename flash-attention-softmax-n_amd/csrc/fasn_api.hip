@@ -66,7 +66,14 @@ int check_view(const fasn_view4& v, bool required, int esize = 2) {
     return FASN_OK;
 }
 
-int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
+// fp32 bias next to 16-bit q / k / v on the vector path (round 5): the head dims whose kernels have the fp32 image instantiation,
+// per pass (0 forward, 1 backward). Everything else keeps the element-load kernels for such a bias.
+bool f32_bias_vector(int D, int pass) {
+    (void)pass;   // (head dim 128: the two-wave backward kernels and the 8-wave forward have no room for 8 KiB images yet)
+    return D == 32 || D == 64;
+}
+
+int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l, int pass = 0) {
     if (a == nullptr) return FASN_EINVAL;
     if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0 || a->D <= 0 || a->Dv <= 0) return FASN_EINVAL;
     if (a->dtype != FASN_DTYPE_F16 && a->dtype != FASN_DTYPE_BF16 && a->dtype != FASN_DTYPE_F32) return FASN_EDTYPE;
@@ -117,7 +124,10 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
         const int al = 4 * esz;  // 4 keys per load
         bool ok = a->bias.stride[3] == 1 && (reinterpret_cast<uintptr_t>(a->bias.ptr) % al) == 0;
         for (int i = 0; i < 3; ++i) ok = ok && ((a->bias.stride[i] * esz) % al == 0);
-        p.bias_vec = (ok && !p.bias_f32 && a->scale > 0.f) ? 1 : 0;  // fp32 bias / scale 0 take the element-load path
+        // scale 0 takes the element-load path; so does an fp32 bias next to 16-bit q / k / v unless this head dim and pass have the fp32 image
+        // instantiation (no dropout, no split-K there), and any bias next to fp32 q / k / v (their kernels have the element-load mode only)
+        const bool f32_ok = !p.bias_f32 || (esize == 2 && !(a->dropout_p > 0.f) && f32_bias_vector(a->D, pass));
+        p.bias_vec = (ok && f32_ok && a->scale > 0.f) ? 1 : 0;
     }
     if (a->mask.ptr) {
         bool ok = a->mask.stride[3] == 1 && (reinterpret_cast<uintptr_t>(a->mask.ptr) % 4) == 0;
@@ -127,7 +137,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
     if (a->bias.ptr && a->bias.stride[0] == 0 && a->B > 1) p.batch_inner = 1;
     p.bias_bytes = p.mask_bytes = 0;
     {   // per-(b,h) slice extents for the buffer descriptors of the vector path; slices of 2 GiB or more use the element path
-        const int64_t bb = a->bias.ptr ? ((int64_t)(a->Sq - 1) * a->bias.stride[2] + a->Sk) * 2 : 0;
+        const int64_t bb = a->bias.ptr ? ((int64_t)(a->Sq - 1) * a->bias.stride[2] + a->Sk) * (p.bias_f32 ? 4 : 2) : 0;
         const int64_t mb = a->mask.ptr ? ((int64_t)(a->Sq - 1) * a->mask.stride[2] + a->Sk) : 0;
         if (bb >= (1ll << 31)) p.bias_vec = 0;
         if (mb >= (1ll << 31)) p.mask_vec = 0;
@@ -202,6 +212,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l) {
 int plan_splitk(const fasn_fwd_args* a, const FwdParams& p, const FwdLaunch& l, int& tps) {
     tps = 0;
     if (l.dtype == FASN_DTYPE_F32 || p.drop_thr || l.mode == MODE_GENERAL_SLOW || l.D > 128) return 1;
+    if (p.bias_f32 && p.bias_vec) return 1;   // (the fp32 bias image has no split-K instantiation)
     if ((l.mode == MODE_KEYPAD || l.mode == MODE_BIAS_KEYPAD) && p.keypad_fallback == MODE_GENERAL_SLOW) return 1;
     const int64_t base_blocks = (int64_t)a->B * a->H * ((a->Sq + 127) / 128);
     int ntiles = (a->Sk + KT - 1) / KT;
@@ -377,7 +388,7 @@ int fasn_bwd(const fasn_bwd_args* a, fasn_stream_t stream) {
     if (a == nullptr) return FASN_EINVAL;
     FwdParams fp;
     FwdLaunch l;
-    int rc = build_fwd(&a->fwd, fp, l);
+    int rc = build_fwd(&a->fwd, fp, l, 1);
     if (rc) return rc;
     if (a->fwd.lse == nullptr || a->delta == nullptr) return FASN_EINVAL;
     if (l.mode == MODE_KEYPAD && l.dtype == FASN_DTYPE_F32) l.mode = MODE_GENERAL_SLOW;   // (the fp32 kernels have the element-load mask path only)

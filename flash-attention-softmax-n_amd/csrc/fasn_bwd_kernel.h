@@ -134,8 +134,11 @@ struct TileDma {
 #ifndef FASN_DQ_SEED_D32
 #define FASN_DQ_SEED_D32 2
 #endif
-template <typename Tag, int D, int QB, int MODE, int OCC, int DROP = 0, int DQ_SEED = (D >= 128 ? FASN_DQ_SEED_D128 : D == 32 ? FASN_DQ_SEED_D32 : 3)>
+// BF32 (round 5): fp32 bias image next to 16-bit q / k / v, as in the forward (fasn_fwd_kernel.h)
+template <typename Tag, int D, int QB, int MODE, int OCC, int DROP = 0, int DQ_SEED = (D >= 128 ? FASN_DQ_SEED_D128 : D == 32 ? FASN_DQ_SEED_D32 : 3), int BF32 = 0>
 __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams bp) {
+    static_assert(!BF32 || mode_has_vbias(MODE), "fp32 bias image: the vector bias modes");
+    constexpr int IMGB = BF32 ? 8192 : 4096, IMGM = (BF32 && !mode_has_vmask(MODE)) ? 0 : 2048, BPC = BF32 ? 16 : 8, BW = BF32 ? 16 : 8;   // (fasn_fwd_kernel.h)
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     const FwdParams& p = bp.f;
@@ -290,17 +293,17 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     // (bias*log2e/c, or -inf where the mask byte is clear) is the S accumulator's start value. An absent operand gets a
     // zero-range descriptor (bias reads 0) / an all-ones OR word (mask keeps everything).
     u32x4 brw, mrw;
-    unsigned bvo[QB][4], mvo[QB][2];
+    unsigned bvo[QB][IMGB / 1024], mvo[QB][2];
     const uint32_t nomask = (VMASK && p.mask == nullptr) ? 0x01010101u : 0u;
     const float binv = VEC ? kLog2e : 0.f;   // Q is pre-scaled: S' = bias*log2e - LSE*log2e + q'.k
-    char* const ldsGB = smem + 4 * TILEB + wave * (QB * 6144);
-    char* const ldsGM = ldsGB + QB * 4096;
+    char* const ldsGB = smem + 4 * TILEB + wave * (QB * (IMGB + IMGM));
+    char* const ldsGM = ldsGB + QB * IMGB;
     const uint32_t ldsGB_a = lds_addr(ldsGB), ldsGM_a = lds_addr(ldsGM);
     auto gen_dma = [&](int t) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lds_dma16(brw, __builtin_amdgcn_readfirstlane(ldsGB_a + qb * 4096 + i * 1024), bvo[qb][i], t * (KT * 2));
+            for (int i = 0; i < IMGB / 1024; ++i) lds_dma16(brw, __builtin_amdgcn_readfirstlane(ldsGB_a + qb * IMGB + i * 1024), bvo[qb][i], t * (KT * (BF32 ? 4 : 2)));
             if (VMASK) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) lds_dma16(mrw, __builtin_amdgcn_readfirstlane(ldsGM_a + qb * 2048 + i * 1024), mvo[qb][i], t * KT);
@@ -308,16 +311,16 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         }
     };
     if (VEC) {
-        const char* bb = p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
+        const char* bb = p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * (BF32 ? 4 : 2) : p.q;
         const char* mb = (VMASK && p.mask) ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
         brw = make_rsrc_words(bb, p.bias ? p.bias_bytes : 0u);
         mrw = make_rsrc_words(mb, (VMASK && p.mask) ? p.mask_bytes : 0u);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int sl = i * 64 + lane, row = sl >> 3, c = (sl & 7) ^ swz_f<64>(row);
-                bvo[qb][i] = (unsigned)(((qw0 + qb * 32 + row) * (int)p.bs[2] + c * 8) * 2);
+            for (int i = 0; i < IMGB / 1024; ++i) {
+                const int sl = i * 64 + lane, row = sl / BPC, c = (sl % BPC) ^ (BF32 ? swz_f<128>(row) : swz_f<64>(row));
+                bvo[qb][i] = (unsigned)((qw0 + qb * 32 + row) * (int)p.bs[2] * (BF32 ? 4 : 2) + c * 16);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
             kp_next = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(kprs, lane, (t + 1) * KT, 0) | kp_or;
         }
         uint32_t mraw[QB][2][4];
-        u32x2 braw[QB][2][4];
+        uint32_t braw[QB][2][BW];   // the lane's 16 keys of a 32-key block: 8 dwords of 16-bit pairs, or 16 fp32 values
         if (VEC) {   // unconditional, also for skipped tiles: the request / wait pattern is the same for every tile
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's image (and its visibility bytes) have landed
             if (KP) {   // the next tile's bytes are requested after the wait, so it does not cover their latency
@@ -368,10 +371,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const u32x4 w = *LDS_PTR(const u32x4, ldsGB + qb * 4096 + tile_off<64>(l31, kb * 4 + 2 * hi + j));
-                        braw[qb][kb][2 * j] = u32x2{w[0], w[1]};
-                        braw[qb][kb][2 * j + 1] = u32x2{w[2], w[3]};
+                    for (int j = 0; j < BW / 4; ++j) {
+                        const u32x4 w = *LDS_PTR(const u32x4, ldsGB + qb * IMGB + (BF32 ? tile_off<128>(l31, kb * 8 + 4 * hi + j) : tile_off<64>(l31, kb * 4 + 2 * hi + j)));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) braw[qb][kb][4 * j + e] = w[e];
                     }
                     if (VMASK) {
                         const u32x4 w = *LDS_PTR(const u32x4, ldsGM + qb * 2048 + tile_off<32>(l31, kb * 2 + hi));
@@ -418,8 +421,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         if (VEC) {
-                            const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
-                            const float v = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), binv, -lse2[qb]);
+                            const uint32_t w = braw[qb][kb][BF32 ? r : (r >> 1)];
+                            const float v = __builtin_fmaf(BF32 ? __uint_as_float(w) : E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), binv, -lse2[qb]);
                             if (VMASK) sacc[qb][r] = ((mraw[qb][kb][r >> 2] >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
                             else if (KP) sacc[qb][r] = (((uint32_t)(kp_bits >> (32 * kb + 16 * hi)) >> r) & 1u) ? v : -INFINITY;   // key-permuted rows: register r = key 16*hi + r
                             else sacc[qb][r] = v;
@@ -576,8 +579,12 @@ constexpr int QT = 64;  // query rows per tile
 // of all query heads of its group, one head after the other, into the same fp32 accumulators: dK / dV come out per K/V head.
 // DH = 2 (D = 256): two workgroups per key block, each with the full S / dP but HALF of the features of dK and dV (2 x 64 instead of
 // 2 x 128 accumulator registers); the grid is doubled, block 2j + v owns feature half v.
-template <typename Tag, int D, int KB, int MODE, int OCC, int DROP = 0, int GQA = 0, int DH = 1>
+// BF32 (round 5): fp32 bias next to 16-bit q / k / v on the vector path - the workgroup's additive tile is [64 rows][BN keys] fp32, row major
+// (bias, or -inf where the mask byte is clear), moved in 16-byte pieces (4 keys), and a lane reads the 16 rows of ITS key column with plain
+// ds_read_b32 (consecutive lanes, consecutive dwords: no bank conflict) instead of the 16-bit transposing read
+template <typename Tag, int D, int KB, int MODE, int OCC, int DROP = 0, int GQA = 0, int DH = 1, int BF32 = 0>
 __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams bp) {
+    static_assert(!BF32 || mode_has_vbias(MODE), "fp32 additive tile: the vector bias modes");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     const FwdParams& p = bp.f;
@@ -742,32 +749,34 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     constexpr bool VEC = mode_is_vector(MODE);      // MODE_GENERAL, MODE_BIAS_KEYPAD (the additive tile is the bias alone; the mask is a per-lane flag)
     constexpr bool VMASK = mode_has_vmask(MODE);
     constexpr int BN_ = 4 * KB * 32;
-    constexpr int ADDB = QT * BN_ * 2;              // bytes of one additive tile = BN_/128 swizzled [64][128] images
-    constexpr int ACH = (QT * BN_ / 8) / 256;       // 8-key chunks per thread
+    constexpr int KPC = BF32 ? 4 : 8;               // keys per 16-byte chunk of the bias
+    constexpr int ADDB = QT * BN_ * (BF32 ? 4 : 2); // bytes of one additive tile = BN_/128 swizzled [64][128] 16-bit images, or [64][BN_] fp32 row major
+    constexpr int ACH = (QT * BN_ / KPC) / 256;     // chunks per thread
     char* const ldsAdd = smem + 4 * TILEB + 4 * QT * 4;   // [2][ADDB]
     __amdgpu_buffer_rsrc_t brs, mrs;
     unsigned abvo0 = 0, amvo0 = 0;   // chunk 0 of this thread; chunk i is RSTEP rows further down (wave-uniform offset)
-    constexpr int RSTEP = 256 / (BN_ / 8);
-    const int arow0 = tid / (BN_ / 8), akc = tid % (BN_ / 8);
+    constexpr int RSTEP = 256 / (BN_ / KPC);
+    const int arow0 = tid / (BN_ / KPC), akc = tid % (BN_ / KPC);
     u32x4 stA[ACH];
-    u32x2 stM[ACH];
+    u32x2 stM[ACH];   // mask bytes of the chunk's keys (fp32: the low word only)
     const uint32_t nomask = (!VMASK || p.mask == nullptr) ? 0x01010101u : 0u;
     const float binv = VEC ? kLog2e : 0.f;   // K is pre-scaled: S' = add*log2e - LSE*log2e + q.k'
     const uint32_t ninf16 = std::is_same<Tag, bf16_tag>::value ? 0xFF80u : 0xFC00u;   // -inf in the 16-bit type
     if (VEC) {
-        const char* bb = p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
+        const char* bb = p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * (BF32 ? 4 : 2) : p.q;
         const char* mb = (VMASK && p.mask) ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
         brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bb), 0, p.bias ? p.bias_bytes : 0u, 0x00020000);
         mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mb), 0, (VMASK && p.mask) ? p.mask_bytes : 0u, 0x00020000);
-        abvo0 = (unsigned)((arow0 * p.bs[2] + akc * 8) * 2);
-        amvo0 = (unsigned)(arow0 * p.ms[2] + akc * 8);
+        abvo0 = (unsigned)((arow0 * p.bs[2] + akc * KPC) * (BF32 ? 4 : 2));
+        amvo0 = (unsigned)(arow0 * p.ms[2] + akc * KPC);
     }
     auto add_gload = [&](int row0) {
         const int kcol0 = kblk * BN_;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            stA[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, abvo0, ((row0 + i * RSTEP) * (int)p.bs[2] + kcol0) * 2, 0);
-            if (VMASK) stM[i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, amvo0, (row0 + i * RSTEP) * (int)p.ms[2] + kcol0, 0);
+            stA[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, abvo0, ((row0 + i * RSTEP) * (int)p.bs[2] + kcol0) * (BF32 ? 4 : 2), 0);
+            if (VMASK && BF32) stM[i] = u32x2{__builtin_amdgcn_raw_buffer_load_b32(mrs, amvo0, (row0 + i * RSTEP) * (int)p.ms[2] + kcol0, 0), 0u};
+            else if (VMASK) stM[i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, amvo0, (row0 + i * RSTEP) * (int)p.ms[2] + kcol0, 0);
             else stM[i] = u32x2{0u, 0u};
         }
     };
@@ -775,6 +784,12 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             u32x4 o;
+            if constexpr (BF32) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) o[w] = (((stM[i][0] | nomask) >> (8 * w)) & 0xffu) ? stA[i][w] : 0xFF800000u;   // -inf where the key's mask byte is clear
+                *LDS_PTR(u32x4, ldsAdd + buf * ADDB + (arow0 + i * RSTEP) * (BN_ * 4) + akc * 16) = o;
+                continue;
+            }
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const uint32_t mw = (stM[i][w >> 1] | nomask) >> (16 * (w & 1));   // mask bytes of keys 2w, 2w+1
@@ -875,6 +890,13 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 for (int kb = 0; kb < KB; ++kb) {
                     if (VEC) {   // (all lanes take part in the transposed read; a lane whose key is padded overrides its values below)
                         const int cb = wave * KB + kb;   // this wave's 32-key column block inside the additive tile
+                        if constexpr (BF32) {   // register r = row (r&3) + 8(r>>2) + 4hi of the 32-row block, column = this lane's key
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float av = *LDS_PTR(const float, tA + (qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * (BN_ * 4) + (cb * 32 + l31) * 4);
+                                sacc[kb][r] = __builtin_fmaf(av, binv, lr[r]);
+                            }
+                        } else
 #pragma unroll
                         for (int t2 = 0; t2 < 2; ++t2) {
                             vec8 av = lds_read_trfrag<E, 128>(tA + (cb >> 2) * (QT * 256), qb * 32 + 16 * t2, cb & 3, lane);

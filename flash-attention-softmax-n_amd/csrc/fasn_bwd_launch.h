@@ -29,8 +29,10 @@ extern int g_bwd_variant;
 #endif
 
 // WS = 1: dK / dV by the two-wave kernel (fasn_bwd_dkdv_ws.h); not for dropout or the element-load mode
-template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, int DROP = 0, int WS = 0, int DH = 1>
+// BF32 = 1 (round 5): the one-wave kernels' fp32 bias instantiations (fp32 bias next to 16-bit q / k / v on the vector path; D <= 64)
+template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, int DROP = 0, int WS = 0, int DH = 1, int BF32 = 0>
 int launch_bwd_one(BwdParams p, hipStream_t s) {
+    static_assert(!BF32 || (WS == 0 && DROP == 0 && DH == 1), "fp32 bias image: one-wave kernels without dropout");
     const int nbh = p.f.B * p.f.H;
     {   // delta
         constexpr int RPB = 256 / (D / 8);
@@ -51,9 +53,9 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     }
     if (!dq_done) {   // dQ
         constexpr int BM = 4 * QB * 32;
-        constexpr int smem = 4 * KT * D * 2 + (mode_is_vector(MODE) ? 4 * QB * 6144 : 0);   // + per-wave bias / mask images
+        constexpr int smem = 4 * KT * D * 2 + (mode_is_vector(MODE) ? 4 * QB * ((BF32 ? 8192 : 4096) + ((BF32 && !mode_has_vmask(MODE)) ? 0 : 2048)) : 0);   // + per-wave bias / mask images
         p.nblk = (p.f.Sq + BM - 1) / BM;
-        constexpr auto kern = &fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q, DROP>;
+        constexpr auto kern = &fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q, DROP, (D >= 128 ? FASN_DQ_SEED_D128 : D == 32 ? FASN_DQ_SEED_D32 : 3), BF32>;
         ensure_smem<kern>(smem);
         // causal: block r and block nblk-1-r in one workgroup (equal workgroups for the in-order dispatcher, see fasn_fwd_kernel.h)
         p.f.pair = (MODE == MODE_CAUSAL && !DROP && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * OCC_Q)) ? 1 : 0;
@@ -83,14 +85,14 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     }
     {   // dK, dV
         constexpr int BN = 4 * KB * 32;
-        constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (mode_is_vector(MODE) ? 2 * QT * BN * 2 : 0);
+        constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (mode_is_vector(MODE) ? 2 * QT * BN * (BF32 ? 4 : 2) : 0);
         p.nblk = (p.f.Sk + BN - 1) / BN;
         if (p.f.kvg > 1) {
-            constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 1, DH>;
+            constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 1, DH, BF32>;
             ensure_smem<kern>(smem);
             FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg) * DH)), dim3(256), smem, s, p);
         } else {
-            constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 0, DH>;
+            constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 0, DH, BF32>;
             ensure_smem<kern>(smem);
             p.f.pair = (MODE == MODE_CAUSAL && !DROP && DH == 1 && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * OCC_K)) ? 1 : 0;
             FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh * DH)), dim3(256), smem, s, p);
@@ -121,6 +123,12 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
             case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_KEYPAD, OCC_Q, OCC_K, 1, WS>(p, s);
             case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1, 1>(p, s);
             default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 1>(p, s);   // vector mask / bias
+        }
+    }
+    if constexpr (D <= 128) {   // fp32 bias next to 16-bit q / k / v on the vector path (fasn_api.hip: f32_bias_vector); D = 128: the ONE-wave kernels (the two-wave ones have no LDS left for 8 KiB images)
+        if (p.f.bias_f32 && p.f.bias_vec) {
+            if (mode == MODE_BIAS_KEYPAD) return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), 1, 0, 0, 1, 1>(p, s);
+            return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), 1, 0, 0, 1, 1>(p, s);   // bias alone or bias + dense mask
         }
     }
     switch (mode) {

@@ -166,6 +166,13 @@ FASN_DEV u32x4 make_rsrc_words(const void* base, uint32_t bytes) {
     r[3] = 0x00020000u;
     return r;
 }
+// the lane id from the execution mask (v_mbcnt_lo / _hi with all lanes active): a value nothing has to keep live
+// (volatile asm: the builtins are pure, so the compiler would fold every call into ONE value computed at kernel entry and keep that live)
+FASN_DEV int fresh_lane_id() {
+    int x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
 FASN_DEV uint32_t lds_addr(const void* p) {
     return (uint32_t)reinterpret_cast<uintptr_t>(LDS_PTR(const char, p));
 }

@@ -13,6 +13,14 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         }
     }
 #endif
+    if (p.bias_f32) {   // fp32 bias next to 16-bit q / k / v: the fp32 image instantiations on the 4-wave kernel (8 KiB images for eight waves do not fit next to three K/V buffers)
+        switch (l.mode) {
+            case MODE_GENERAL: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 1, 4, 2, 2, 0, 1, 0, 1>(p, s);
+            case MODE_GENERAL_B: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_B, 1, 4, 2, 2, 0, 1, 0, 1>(p, s);
+            case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 128, 1, MODE_BIAS_KEYPAD, 1, 4, 2, 2, 0, 1, 0, 1>(p, s);
+            default: break;
+        }
+    }
     switch (l.mode) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);
         case MODE_GENERAL_B:   // the bias-only instantiation spills (37 VGPRs) at D = 128: the bias + key-padding kernel with every key kept

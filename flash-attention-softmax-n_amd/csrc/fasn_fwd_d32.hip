@@ -3,6 +3,14 @@
 namespace fasn {
 template <typename Tag>
 static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
+    if (p.bias_f32) {   // fp32 bias next to 16-bit q / k / v: the fp32 image instantiations
+        switch (l.mode) {
+            case MODE_GENERAL: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, 1, 4, 0, 2, 0, 1, 0, 1>(p, s);
+            case MODE_GENERAL_B: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_B, 1, 4, 0, 2, 0, 1, 0, 1>(p, s);
+            case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 32, 2, MODE_BIAS_KEYPAD, 1, 4, 0, 2, 0, 1, 0, 1>(p, s);
+            default: break;
+        }
+    }
     switch (l.mode) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, 1, 4, 0, 2>(p, s);
         case MODE_GENERAL_B: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_B, 1, 4, 0, 2>(p, s);

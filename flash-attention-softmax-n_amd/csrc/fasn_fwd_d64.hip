@@ -19,6 +19,14 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         }
     }
 #endif
+    if (p.bias_f32) {   // fp32 bias next to 16-bit q / k / v (fasn_api.hip: f32_bias_vector): the fp32 image instantiations
+        switch (l.mode) {
+            case MODE_GENERAL: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 4, 0, 2, 0, 1, 0, 1>(p, s);
+            case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_B, 2, 4, 0, 2, 0, 1, 0, 1>(p, s);
+            case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 64, 1, MODE_BIAS_KEYPAD, 2, 4, 0, 2, 0, 1, 0, 1>(p, s);
+            default: break;
+        }
+    }
     switch (l.mode) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 4, 0, 2>(p, s);
         case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_B, 2, 4, 0, 2>(p, s);
@@ -34,7 +42,8 @@ static int dev_variant(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         // ---- production tuning points
         case 100: return launch_fwd_mode<Tag, 64, 2, 2>(p, l.mode, s);
         case 90: return launch_fwd_cfg<Tag, 64, 2, 2, 4, 2, 2>(p, l.mode, s);   // the plain kernel's tuning point for any mode (causal: paired blocks by the shipped rule)
-        case 91: return launch_fwd_cfg<Tag, 64, 1, 3, 4, 2, 2>(p, l.mode, s);   // the causal kernel's tuning point for any mode
+        case 91: return launch_fwd_cfg<Tag, 64, 1, 3, 4, 2, 2>(p, l.mode, s);   // the round-4 causal tuning point (32 rows per wave, three workgroups per CU) for any mode
+        case 92: if (l.mode == MODE_CAUSAL) return launch_fwd_one<Tag, 64, 2, MODE_CAUSAL, 2, 4, 2, 2, 0, 1, 1>(p, s); break;   // causal: folded two-phase walk whatever the launch size
         case 1: return launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);
         // ---- alternatives kept for A/B measurements (tools/fasn_harness bench ... <variant>)
         case 2: return launch_fwd_mode<Tag, 64, 2, 1>(p, l.mode, s);
@@ -81,6 +90,11 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.variant != 0) return dev_variant<Tag>(p, l, s);
 #endif
     if (big_plain) return launch_fwd_cfg<Tag, 64, 2, 2, 4, 2, 2>(p, l.mode, s);
+    // causal launches of many rounds (or of long blocks) at the plain kernel's tuning point with the folded two-phase walk (round 5; same box,
+    // profiles/r05_causal_forward_folded_two_phase_ab.log: C5 2.28 -> 2.23 ms, (4,32,8192,64) 1.056 -> 1.038, (2,16,16384,64) 1.030 -> 0.992;
+    // at two rounds of 4096-key blocks - C3 - the 32-row kernel's finer workgroups still win: 0.310 against 0.318 ms)
+    if (l.mode == MODE_CAUSAL && p.Sq >= 256 && (blocks_qb2 >= 4096 || (blocks_qb2 >= 2048 && p.Sq >= 8192)))
+        return launch_fwd_one<Tag, 64, 2, MODE_CAUSAL, 2, 4, 2, 2, 0, 1, 1>(p, s);
     return launch_fwd_cfg<Tag, 64, 1, 3, 4, 2, 2>(p, l.mode, s);
 }
 int launch_fwd_d64(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {

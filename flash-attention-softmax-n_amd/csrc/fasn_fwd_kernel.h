@@ -32,9 +32,6 @@
 #ifndef FASN_FWD_UNR2
 #define FASN_FWD_UNR2 1
 #endif
-#ifndef FASN_PIPESEED
-#define FASN_PIPESEED 1
-#endif
 namespace fasn {
 
 // MODE_GENERAL: mask and/or bias through 4-key vector (buffer) loads - needs key stride 1 and aligned rows (bias_vec /
@@ -198,8 +195,21 @@ FASN_DEV bool kpair_plan(const FwdParams& p, char* scratch, int tid, int slot, i
 // RING: 2 = no staging registers at all: `buffer_load_dwordx4 ... lds` moves each 16-byte chunk straight from HBM/L2 into
 // the LDS tile image (LDS address = wave base + 16*lane, so the swizzle is applied by choosing WHICH global chunk a lane
 // fetches), three LDS tile buffers, loads issued two tiles ahead, `s_waitcnt vmcnt` before the barrier that publishes a tile.
-template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int DROP = 0, int RING = 0, int SPLIT = 0, int SEED = 0, int VH = 1>
+// FOLD (round 5, causal launches at the plain kernel's tuning point: 64 rows per wave, two workgroups per CU): (i) the key walk of a block is
+// cut in two - the tiles every row of the block sees run the plain tile body (no compare, no per-wave classification, loop unrolled
+// by its buffers), the up to five tiles that touch the block's diagonal run a second instantiation of the body that classifies per
+// 32-row block; (ii) the wave's two 32-row blocks are block `wave` and block `7 - wave` of the workgroup's eight ("folded"), so every wave
+// has work in every diagonal step (with contiguous rows wave 0 sat idle for three of the four steps, behind the barrier) and the diagonal
+// steps cost about half a full step each instead of more than a full one (the exact softmax path of a 64-row wave on a tile of which it
+// needs a quarter). Reference: the causal bound of flash_attn_triton.py:89-112 (start_n loop to (start_m + 1) * BLOCK_M).
+// BF32 (round 5): the additive bias of a vector general mode holds fp32 elements next to 16-bit q / k / v (what Hugging Face models hand over
+// as additive masks, reference core/flash_attn.py:100-113): the wave's bias image is [32 rows][64 keys] fp32 (8 KiB, rows of 256 bytes swizzled
+// like a D = 128 tile), moved by the same coalesced 16-byte LDS-DMA pieces, read 64 bytes per 32-key block and lane, and the start value of a
+// score is one fma on the fp32 value - no 16-bit unpack. Round 4 sent these calls through the element-load kernels (3-5 x slower).
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int PRIO = 0, int DROP = 0, int RING = 0, int SPLIT = 0, int SEED = 0, int VH = 1, int FOLD = 0, int BF32 = 0>
 __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams p) {
+    static_assert(!BF32 || (mode_has_vbias(MODE) && !SPLIT), "fp32 bias image: the vector bias modes");
+    static_assert(!FOLD || (MODE == MODE_CAUSAL && QB == 2 && RING == 2 && !SPLIT && !DROP && VH == 1 && D <= 64), "folded two-phase walk: the causal 64-rows-per-wave kernel");
     static_assert(!SEED || MODE != MODE_GENERAL_SLOW, "seeded accumulators: not for the element-load kernels");
     static_assert(!SPLIT || (RING != 1 && DROP == 0), "split-K: single-set or direct-to-LDS staging");
     // VH = 2 (D = 256): two workgroups per query block, each with the full QK^T and softmax but HALF of the output features
@@ -295,6 +305,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * BM;
     const int qw0 = q0 + wave * (QB * 32);  // first row of this wave
+    // first row of the wave's 32-row block qb: contiguous, or (FOLD) block `wave` and block `2 NW - 1 - wave` of the workgroup's 2 NW blocks
+    auto rowb = [&](int qb) { return FOLD ? q0 + (qb == 0 ? wave : 2 * NW - 1 - wave) * 32 : qw0 + qb * 32; };
 
     const char* qbase = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
     const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2;
@@ -314,7 +326,11 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // Key-padding mask: the workgroup turns the mask bytes of its key range into one visibility word per K/V tile, ONCE, in LDS
     // (thread c: 16 bytes -> 16 bits; a tile then costs one uniform ds_read_b64 instead of a global load per wave and tile, whose
     // compiler-counted wait also drained the K/V prefetch). Trailing tiles without a visible key are not walked at all.
-    uint64_t* const ldsKP = reinterpret_cast<uint64_t*>(smem + 2 * (RING == 2 ? 3 : 2) * (KT * D * 2) + (mode_is_vector(MODE) ? NW * QB * 6144 : 0));   // [kFwdKpMaxTiles]
+    constexpr int IMGB = BF32 ? 8192 : 4096;                          // bias image of one 32-row block and tile: [32 rows][64 keys] 16 bit / fp32
+    constexpr int IMGM = (BF32 && !mode_has_vmask(MODE)) ? 0 : 2048;   // mask image [32 rows][64 bytes] (the fp32 instantiations without a mask operand do not reserve it)
+    constexpr int BPC = BF32 ? 16 : 8;                                 // 16-byte chunks per bias image row
+    constexpr int BW = BF32 ? 16 : 8;                                  // dwords a lane holds per 32-key block (16 keys)
+    uint64_t* const ldsKP = reinterpret_cast<uint64_t*>(smem + 2 * (RING == 2 ? 3 : 2) * (KT * D * 2) + (mode_is_vector(MODE) ? NW * QB * (IMGB + IMGM) : 0));   // [kFwdKpMaxTiles]
     if (KP) {
         kp_build_words(ldsKP, p.mask == nullptr ? nullptr : p.mask + (b * p.ms[0] + h * p.ms[1]), p.Sk, ntiles, tid, NT);
         __syncthreads();
@@ -345,7 +361,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     vec8 qf[QB][KS];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const int row = qw0 + qb * 32 + l31;
+        const int row = rowb(qb) + l31;
         const bool ok = row < p.Sq;
         const char* rp = qbase + (int64_t)row * p.qs[2] * 2 + hi * 16;
 #pragma unroll
@@ -428,11 +444,14 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     for (int qb = 0; qb < ((SEED && !VEC) ? QB : 1); ++qb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mseed[qb][r] = 0.f;
+    const int hi_p = FOLD ? (fresh_lane_id() >> 5) : hi;
+    float n_p = p.n;
+    if constexpr (FOLD) asm volatile("" : "+s"(n_p));   // (per pass: not hoisted in front of the pass loop and parked in scratch)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const bool sink = p.n > 0.f && split == 0;
+        const bool sink = n_p > 0.f && split == 0;
         m_run[qb] = sink ? 0.f : -INFINITY;
-        l_run[qb] = (sink && hi == 0) ? p.n : 0.f;  // the two half-lanes' partial sums are added at the end
+        l_run[qb] = (sink && hi_p == 0) ? n_p : 0.f;  // the two half-lanes' partial sums are added at the end
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -445,7 +464,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     //       a per-lane byte offset of this lane's row + its 4*hi keys; 4 keys per load.
     // SLOW: per-lane row pointers, one element per load.
     u32x4 brw, mrw;
-    unsigned bvo[QB][4], mvo[QB][2];
+    unsigned bvo[QB][IMGB / 1024], mvo[QB][2];
     const char* bptr[QB];
     const uint8_t* mptr[QB];
     const bool has_bias = VBIAS || (SLOW && p.bias != nullptr);
@@ -457,9 +476,9 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             if (VEC) {
                 // slot s = 64*i + lane of the wave's LDS image <- the 16-byte chunk that belongs there (swizzled like the K/V tiles)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int sl = i * 64 + lane, row = sl >> 3, c = (sl & 7) ^ swz_f<64>(row);
-                    bvo[qb][i] = (unsigned)(((qw0 + qb * 32 + row) * (int)p.bs[2] + c * 8) * 2);
+                for (int i = 0; i < IMGB / 1024; ++i) {
+                    const int sl = i * 64 + lane, row = sl / BPC, c = (sl % BPC) ^ (BF32 ? swz_f<128>(row) : swz_f<64>(row));
+                    bvo[qb][i] = (unsigned)((qw0 + qb * 32 + row) * (int)p.bs[2] * (BF32 ? 4 : 2) + c * 16);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -473,7 +492,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             }
         }
         if (VEC) {
-            const char* bb = has_bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q;
+            const char* bb = has_bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * (BF32 ? 4 : 2) : p.q;
             const char* mb = has_mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q;
             brw = make_rsrc_words(bb, has_bias ? p.bias_bytes : 0u);
             mrw = make_rsrc_words(mb, has_mask ? p.mask_bytes : 0u);
@@ -484,15 +503,15 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // and made the texture addresser the bottleneck), into a wave-private image next to the K/V tiles; the lane then reads
     // its row's 32 + 16 bytes per 32-key block with ds_read_b128. Single-buffered: tile t+1 is requested right after
     // tile t has been read into registers, and lands while tile t is computed.
-    char* const ldsGB = smem + 2 * NBUF * TILEB + wave * (QB * 6144);   // [QB][32 rows][128 B] bias
-    char* const ldsGM = ldsGB + QB * 4096;                                // [QB][32 rows][64 B] mask
+    char* const ldsGB = smem + 2 * NBUF * TILEB + wave * (QB * (IMGB + IMGM));   // [QB][32 rows][128 / 256 B] bias
+    char* const ldsGM = ldsGB + QB * IMGB;                                         // [QB][32 rows][64 B] mask
     const uint32_t ldsGB_a = lds_addr(ldsGB), ldsGM_a = lds_addr(ldsGM);
     auto gen_dma = [&](int t) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             if (VBIAS) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) lds_dma16(brw, __builtin_amdgcn_readfirstlane(ldsGB_a + qb * 4096 + i * 1024), bvo[qb][i], t * (KT * 2));
+                for (int i = 0; i < IMGB / 1024; ++i) lds_dma16(brw, __builtin_amdgcn_readfirstlane(ldsGB_a + qb * IMGB + i * 1024), bvo[qb][i], t * (KT * (BF32 ? 4 : 2)));
             }
             if (VMASK) {
 #pragma unroll
@@ -516,10 +535,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile 0 (and Q) landed; tile 1 in flight
         }
     } else if (ntiles > t_begin) {
-        stage_load(t_begin, Set0{});
+        stage_load(phys(t_begin), Set0{});   // (phys: the rotated second walk of a length pair, identity elsewhere)
         stage_store(0, Set0{});
-        if (RING) stage_load(1, Set1{});   // tile 1 in flight in the second set
-        if (VEC) gen_dma(t_begin);
+        if (RING) stage_load(phys(1), Set1{});   // tile 1 in flight in the second set
+        if (VEC) gen_dma(phys(t_begin));
     }
     __syncthreads();
 #pragma unroll
@@ -563,37 +582,22 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // and the request instructions then sit where the wave waits for its neighbours anyway instead of in front of the tile's
     // first MFMA (both waves of a SIMD belong to one workgroup and run in phase, so nothing else covered them there).
     constexpr bool LATE = VEC && RING == 2;
-    // PIPESEED (round 5; bias + key-padding kernel): the start values of tile t+1 (bias * log2e - m, one fma and one 16-bit -> fp32
-    // unpack per score) are built BESIDE the PV MFMAs of tile t instead of at the top of tile t+1, where they stood right behind the
-    // barrier with both waves of a SIMD doing VALU work at once and the matrix pipe idle (about a quarter of the tile).
-    // They wait in the QK^T accumulator tuple of the next tile (32 registers per row block, 16 more than the raw image they replace).
-    constexpr bool PIPESEED = LATE && MODE == MODE_BIAS_KEYPAD && !DROP && QB == 1 && SEED && FASN_PIPESEED;
-    f32x16 seed_n[PIPESEED ? QB : 1][2];
-    auto build_seeds = [&](f32x16 (&dst)[PIPESEED ? QB : 1][2], const u32x2 (&br)[QB][2][4], auto KB_) {   // start values of key block KB_ of the NEXT tile from its image
-        constexpr int kb = decltype(KB_)::value;
-#pragma unroll
-        for (int qb = 0; qb < (PIPESEED ? QB : 1); ++qb) {
-            const float mneg = (m_run[qb] != -INFINITY) ? -m_run[qb] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t w = br[qb][kb][r >> 2][(r & 3) >> 1];
-                dst[qb][kb][r] = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), kLog2e, mneg);
-            }
-        }
-    };
+    // (Round 5, measured and not kept - profiles/r05_c4_forward_seeds_beside_pv_ab.log: the start values of tile t+1 built beside the PV MFMAs
+    // of tile t instead of at the top of tile t+1. Config 4 forward 4.05 ms against 4.00 ms: with two waves per SIMD the other wave's MFMAs
+    // already cover this wave's VALU burst behind the barrier, and the same VALU work between the wave's OWN MFMAs only lengthens them.)
     uint32_t mraw_c[QB][2][4];
-    u32x2 braw_c[QB][2][4];
-    auto image_to_regs = [&](uint32_t (&mr)[QB][2][4], u32x2 (&br)[QB][2][4]) {
+    uint32_t braw_c[QB][2][BW];   // the lane's 16 keys of a 32-key block: 8 dwords of 16-bit pairs, or 16 fp32 values
+    auto image_to_regs = [&](uint32_t (&mr)[QB][2][4], uint32_t (&br)[QB][2][BW]) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 if (VBIAS) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const u32x4 w = *LDS_PTR(const u32x4, ldsGB + qb * 4096 + tile_off<64>(l31, kb * 4 + 2 * hi + j));
-                        br[qb][kb][2 * j] = u32x2{w[0], w[1]};
-                        br[qb][kb][2 * j + 1] = u32x2{w[2], w[3]};
+                    for (int j = 0; j < BW / 4; ++j) {
+                        const u32x4 w = *LDS_PTR(const u32x4, ldsGB + qb * IMGB + (BF32 ? tile_off<128>(l31, kb * 8 + 4 * hi + j) : tile_off<64>(l31, kb * 4 + 2 * hi + j)));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) br[qb][kb][4 * j + e] = w[e];
                     }
                 }
                 if (VMASK) {
@@ -607,22 +611,22 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         image_to_regs(mraw_c, braw_c);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         gen_dma(phys(t_begin + 1));
-        if constexpr (PIPESEED) {
-            build_seeds(seed_n, braw_c, std::integral_constant<int, 0>{});
-            build_seeds(seed_n, braw_c, std::integral_constant<int, 1>{});
-        }
     }
 
     // one K/V tile; LSET = register set that receives the prefetch issued here, SSET = set written to LDS at the end
-    auto tile_body = [&](const int t, auto LSET, auto SSET) {
+    // DIAG_ (FOLD kernels): the instantiation for the tiles that touch the block's diagonal - run-time LDS buffer index, per-32-row-block
+    // classification; the main walk (DIAG_ false) of a FOLD kernel sees fully visible tiles only and tests nothing
+    const int lane_o = lane, l31_o = l31, hi_o = hi;   // (the names `compute` shadows)
+    auto tile_body = [&](const int t, auto LSET, auto SSET, auto DIAG_) {
+        constexpr bool DIAG = decltype(DIAG_)::value;
         // RING 1: the loop is unrolled by two (even tile: LSET = set 0, odd tile: LSET = set 1), so the LDS buffer index is a
         // compile-time constant there and buf*TILEB folds into the ds_read immediate offsets instead of two VALU per read
         // RING 2: the loop is unrolled by three and LSET carries the tile's LDS buffer (t % 3) as a compile-time constant, so the
         // buffer offset folds into the ds_read immediates and the DMA's M0 values instead of two VALU per LDS address
         // (D <= 64 and the plain 8-wave D = 128 kernel; the D = 128 mask / bias and 4-wave kernels measured 1-2 % slower with the
         // tripled loop body, instruction cache)
-        const int buf = (UNR3 || UNR2) ? decltype(LSET)::value : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1)));
-        const int buf2 = UNR3 ? (decltype(LSET)::value + 2) % 3 : (t + 2) % 3;   // RING 2: buffer of the tile requested now
+        const int buf = ((UNR3 || UNR2) && !DIAG) ? decltype(LSET)::value : (RING == 2 ? t % 3 : ((RING == 1 && QB == 1) ? decltype(LSET)::value : (t & 1)));
+        const int buf2 = (UNR3 && !DIAG) ? (decltype(LSET)::value + 2) % 3 : (t + 2) % 3;   // RING 2: buffer of the tile requested now
         const int k0 = phys(t) * KT;
         if (RING == 2 && !VEC) stage_direct(phys(t + 2), buf2);   // past-the-end tiles are out of range for the descriptor
         else if (!VEC && (RING || t + 1 < ntiles)) stage_load(t + 1 + RING, LSET);
@@ -635,11 +639,23 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         // wave-uniform tile classification
         bool skip = false;       // no visible element for this wave
         bool need_mask = false;  // some element needs the element-wise path
-        if (causal) {
+        if (causal && !FOLD) {
             skip = k0 > wave_last_vis;
             need_mask = (k0 + KT - 1) > wave_first_vis;
         }
-        if (k0 + KT > p.Sk) need_mask = true;
+        if (k0 + KT > p.Sk && !(FOLD && !DIAG)) need_mask = true;   // (a FOLD kernel's main walk ends in front of the diagonal: every key below Sk)
+        // per 32-row block (FOLD, diagonal tiles): hidden altogether / needs the element-wise path
+        bool skipq[QB], maskq[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            skipq[qb] = false;
+            maskq[qb] = need_mask;
+            if (FOLD && DIAG) {
+                const int first_vis = rowb(qb) + coff;   // last visible key of the block's first row
+                skipq[qb] = k0 > first_vis + 31;
+                maskq[qb] = need_mask || (k0 + KT - 1) > first_vis;
+            }
+        }
         if (KP && kp_bits == 0) skip = true;
         // short query blocks (decode shapes): a wave without rows only helps staging the tiles (QB = 1 kernels: the QB = 2
         // ones are only dispatched for Sq >= 256 and keep their register allocation)
@@ -647,42 +663,39 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 
         // VEC: mask bytes of this lane's elements, 4 consecutive keys per load; SLOW: every tile takes the exact path
         uint32_t mraw[QB][2][4];
-        u32x2 braw[QB][2][4];
-        if (SLOW) need_mask = true;
-        if (PIPESEED) {   // the start values of this tile were built beside the PV MFMAs of the tile before
-            stage_direct(phys(t + 2), buf2);
-        } else if (LATE) {   // the image is already in registers (end of the previous tile); only the requests of this tile remain
+        uint32_t braw[QB][2][BW];
+        if (SLOW) {
+            need_mask = true;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) maskq[qb] = true;
+        }
+        if (LATE) {   // the image is already in registers (end of the previous tile); only the requests of this tile remain
             stage_direct(phys(t + 2), buf2);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        braw[qb][kb][g] = braw_c[qb][kb][g];
-                        mraw[qb][kb][g] = mraw_c[qb][kb][g];
-                    }
+                    for (int g = 0; g < BW; ++g) braw[qb][kb][g] = braw_c[qb][kb][g];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mraw[qb][kb][g] = mraw_c[qb][kb][g];
+                }
         } else if (VEC) {   // unconditional (also for skipped tiles): the request / wait pattern stays the same for every tile
             // this tile's bias / mask image has landed
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             image_to_regs(mraw, braw);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before the next one is requested
             gen_dma(phys(t + 1));                                  // past-the-end tiles are out of range: zeros
-            stage_load(t + 1 + RING, LSET);
+            stage_load(phys(t + 1 + RING), LSET);
         }
-        // PIPESEED: tile t+1 (K / V and image) has landed, tile t+2 stays in flight; the image goes to registers and its slot is requested again
-        auto next_image = [&]() {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
-            image_to_regs(mraw_c, braw_c);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before its slot is requested again
-            gen_dma(phys(t + 2));
-        };
-        if (PIPESEED && skip) {   // (a tile this wave does not compute: the next tile's start values are still due)
-            next_image();
-            build_seeds(seed_n, braw_c, std::integral_constant<int, 0>{});
-            build_seeds(seed_n, braw_c, std::integral_constant<int, 1>{});
-        }
-        if (!skip) {
+        // the tile for the row blocks QLO .. QHI-1 of the wave (all of them, except in the diagonal tiles of a FOLD kernel: one block at a time
+        // there - half the score registers, so that the second instantiation of the body does not push the main walk's registers out)
+        auto compute = [&](auto QLO_, auto QHI_) {
+            constexpr int QLO = decltype(QLO_)::value, QHI = decltype(QHI_)::value;
+            // FOLD, diagonal tiles: everything lane-dependent in here (LDS addresses at a run-time buffer index, row limits) derives from a
+            // fresh lane id, so that none of it is computed in front of the pass loop and parked in scratch across the main walk
+            const int lane_c = (FOLD && DIAG) ? fresh_lane_id() : lane_o;
+            const int lane = lane_c, l31 = (FOLD && DIAG) ? (lane_c & 31) : l31_o, hi = (FOLD && DIAG) ? (lane_c >> 5) : hi_o;
             const char* tK = ldsK + buf * TILEB;
             const char* tV = ldsV + buf * TILEB;
 
@@ -703,21 +716,15 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, s, hi);
                         }
 #pragma unroll
-                        for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
+                        for (int qb = QLO; qb < QHI; ++qb) sacc[qb][kb] = E::mfma(kf, qf[qb][s], sacc[qb][kb]);
                     }
                 }
             };
             if (VEC) {
                 // S' starts from the additive term: bias*log2e/c where the mask byte is set, -inf where it is clear
                 // (S' = add + q.k, y = c*S'): from here on the tile is handled exactly like a plain one
-                if constexpr (PIPESEED) {
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                        for (int kb = 0; kb < 2; ++kb) sacc[qb][kb] = seed_n[qb][kb];
-                } else
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
+                for (int qb = QLO; qb < QHI; ++qb) {
                     const float mneg = (SEED && m_run[qb] != -INFINITY) ? -m_run[qb] : 0.f;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
@@ -725,8 +732,12 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                         for (int r = 0; r < 16; ++r) {
                             float v = mneg;
                             if (VBIAS) {
-                                const uint32_t w = braw[qb][kb][r >> 2][(r & 3) >> 1];
-                                v = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), binv, mneg);
+                                if constexpr (BF32) {
+                                    v = __builtin_fmaf(__uint_as_float(braw[qb][kb][r]), binv, mneg);
+                                } else {
+                                    const uint32_t w = braw[qb][kb][r >> 1];
+                                    v = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), binv, mneg);
+                                }
                             }
                             if (VMASK) v = (((mraw[qb][kb][r >> 2] | nomask) >> (8 * (r & 3))) & 0xffu) ? v : -INFINITY;
                             sacc[qb][kb][r] = v;
@@ -739,7 +750,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
 #pragma unroll
-                            for (int qb = 0; qb < QB; ++qb) sacc[qb][kb][r] = ((w >> r) & 1u) ? sacc[qb][kb][r] : -INFINITY;
+                            for (int qb = QLO; qb < QHI; ++qb) sacc[qb][kb][r] = ((w >> r) & 1u) ? sacc[qb][kb][r] : -INFINITY;
                     }
                 }
                 qk_gemm();
@@ -751,13 +762,13 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     for (int r = 0; r < 16; ++r) {
                         const bool vis_r = ((w >> ((r & 3) + 8 * (r >> 2))) & 1u) != 0;
 #pragma unroll
-                        for (int qb = 0; qb < QB; ++qb) sacc[qb][kb][r] = vis_r ? (SEED ? mseed[qb][r] : 0.f) : -INFINITY;
+                        for (int qb = QLO; qb < QHI; ++qb) sacc[qb][kb][r] = vis_r ? (SEED ? mseed[qb][r] : 0.f) : -INFINITY;
                     }
                 }
                 qk_gemm();
             } else {
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
+                for (int qb = QLO; qb < QHI; ++qb)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -769,7 +780,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass cannot take a 16-register tuple as an asm operand)
             if (SEED && !VEC && FASN_SEED_KEEPALIVE) {
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) asm volatile("" ::"v"(mseed[qb]));
+                for (int qb = QLO; qb < QHI; ++qb) asm volatile("" ::"v"(mseed[qb]));
             }
 #endif
             if (PRIO == 3 && NW == 4) __builtin_amdgcn_s_setprio(0);
@@ -796,8 +807,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             // Only then - wave-uniformly - is the tile redone on the exact path, which re-centres the max.
             vec8 pf[QB][2][2];  // [qb][kb][t]: B operand of the PV MFMA
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                bool exact = need_mask || (SEED && unseeded);
+            for (int qb = QLO; qb < QHI; ++qb) {
+                bool exact = (FOLD ? maskq[qb] : need_mask) || (SEED && unseeded);   // (non-FOLD kernels: the wave-level flag itself - through the per-block array the split-K mask / bias kernel lost the uniform branch and 100 registers)
                 if (!exact) {
                     float rs = 0.f;
                     const float mneg = -m_run[qb];
@@ -842,7 +853,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     else l_run[qb] += rs;
                 }
                 if (exact) {
-                    const int row = qw0 + qb * 32 + l31;
+                    const int row = rowb(qb) + l31;   // (FOLD, diagonal tiles: l31 is the fresh copy of `compute`)
                     const int vis = causal ? (row + coff) : 0x7fffffff;  // last visible key of this row
                     float mx = -INFINITY;
                     if (!SLOW) {
@@ -950,13 +961,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             }
 
             // ---- O^T += V^T P^T
-            if constexpr (PIPESEED) next_image();
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                if constexpr (PIPESEED) {   // the start values of key block kb of tile t+1, independent of everything around them: VALU work for the MFMA shadow
-                    if (kb == 0) build_seeds(seed_n, braw_c, std::integral_constant<int, 0>{});
-                    else build_seeds(seed_n, braw_c, std::integral_constant<int, 1>{});
-                }
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -972,15 +978,20 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             vf = lds_read_trfrag<E, D>(tV, kb * 32 + 16 * t2, dv0 + d, lane);
                         }
 #pragma unroll
-                        for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
+                        for (int qb = QLO; qb < QHI; ++qb) oacc[qb][d] = E::mfma(vf, pf[qb][kb][t2], oacc[qb][d]);
                     }
-                if constexpr (PIPESEED) __builtin_amdgcn_sched_barrier(0);   // (keeps the second key block's V fragments from being hoisted over the first one's: 11 spilled registers without it)
             }
+        };
+        if constexpr (FOLD && DIAG) {
+            if (!skipq[0]) compute(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            if (!skipq[QB - 1]) compute(std::integral_constant<int, QB - 1>{}, std::integral_constant<int, QB>{});
+        } else {
+            if (!skip) compute(std::integral_constant<int, 0>{}, std::integral_constant<int, QB>{});
         }
 
         if (RING == 2) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD + (PIPESEED ? 4 * QB : 0)) : "memory");   // tile t+1 (and its image) is in LDS, tile t+2 (PIPESEED: and the image request behind it) still in flight
-            if (LATE && !PIPESEED) {   // next tile's image -> registers, the one after it requested (ordered by an explicit lgkmcnt wait: a DMA landing before a queued read would be silent corruption)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile t+1 (and its image) is in LDS, tile t+2 still in flight
+            if (LATE) {   // next tile's image -> registers, the one after it requested (ordered by an explicit lgkmcnt wait: a DMA landing before a queued read would be silent corruption)
                 image_to_regs(mraw_c, braw_c);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before its slot is requested again
                 gen_dma(phys(t + 2));
@@ -993,27 +1004,33 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     };
     if (RING == 1) {
         for (int t = 0; t < ntiles; t += 2) {
-            tile_body(t, Set0{}, Set1{});       // even tile: tile t+1 sits in set 1, tile t+2 goes to set 0
-            if (t + 1 < ntiles) tile_body(t + 1, Set1{}, Set0{});
+            tile_body(t, Set0{}, Set1{}, std::false_type{});       // even tile: tile t+1 sits in set 1, tile t+2 goes to set 0
+            if (t + 1 < ntiles) tile_body(t + 1, Set1{}, Set0{}, std::false_type{});
         }
     } else if (UNR3) {
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
         using B2 = std::integral_constant<int, 2>;
-        for (int t = t_begin; t < ntiles; t += 3) {   // t_begin is a multiple of 3 (split-K: tps is a multiple of 6)
-            tile_body(t, B0{}, B0{});
-            if (t + 1 < ntiles) tile_body(t + 1, B1{}, B1{});
-            if (t + 2 < ntiles) tile_body(t + 2, B2{}, B2{});
+        // FOLD: the tiles every row of the block sees (all keys <= the first row's limit) take the plain body, the rest - up to the block's
+        // last visible key - the diagonal body; the LDS buffer of tile t is t % 3 in both
+        const int nmain = FOLD ? max(0, min(ntiles, (q0 + coff + 1) / KT)) : ntiles;
+        for (int t = t_begin; t < nmain; t += 3) {   // t_begin is a multiple of 3 (split-K: tps is a multiple of 6)
+            tile_body(t, B0{}, B0{}, std::false_type{});
+            if (t + 1 < nmain) tile_body(t + 1, B1{}, B1{}, std::false_type{});
+            if (t + 2 < nmain) tile_body(t + 2, B2{}, B2{}, std::false_type{});
+        }
+        if constexpr (FOLD) {
+            for (int t = nmain; t < ntiles; ++t) tile_body(t, B0{}, B0{}, std::true_type{});
         }
     } else if (UNR2) {
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
         for (int t = t_begin; t < ntiles; t += 2) {   // t_begin is even
-            tile_body(t, B0{}, B0{});
-            if (t + 1 < ntiles) tile_body(t + 1, B1{}, B1{});
+            tile_body(t, B0{}, B0{}, std::false_type{});
+            if (t + 1 < ntiles) tile_body(t + 1, B1{}, B1{}, std::false_type{});
         }
     } else {
-        for (int t = t_begin; t < ntiles; ++t) tile_body(t, Set0{}, Set0{});
+        for (int t = t_begin; t < ntiles; ++t) tile_body(t, Set0{}, Set0{}, std::false_type{});
     }
     // direct-to-LDS requests issued for tiles past the end must land before this workgroup's LDS can be handed to another one
     if (RING == 2 || VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1024,7 +1041,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         float* pml = p.part_ml + ((int64_t)bh * p.nsplit + split) * p.Sq * 2;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            const int row = qw0 + qb * 32 + l31;
+            const int row = rowb(qb) + l31;
             const float l_tot = sum_across_halves(l_run[qb]);
             if (row < p.Sq) {
                 if (hi == 0) {
@@ -1046,15 +1063,19 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     }
     // ---- epilogue: O = acc / l, LSE = ln2 * (m + log2 l)
     char* obase = p.o + (b * p.os[0] + h * p.os[1]) * 2;
+    // FOLD: the lane's row and its output addresses are derived HERE from an opaque copy of the lane id - computed before the pass loop
+    // (where the compiler hoists them: they are loop invariant) they would be live across both tile loops, and 13 registers went to scratch
+    const int lane_e = FOLD ? fresh_lane_id() : lane;   // (v_mbcnt: not even the lane id has to stay live)
+    const int l31e = FOLD ? (lane_e & 31) : l31, hie = FOLD ? (lane_e >> 5) : hi;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const int row = qw0 + qb * 32 + l31;
+        const int row = rowb(qb) + l31e;
         const float l_tot = sum_across_halves(l_run[qb]);
         const float inv = l_tot > 0.f ? (DROP ? p.drop_scale : 1.0f) / l_tot : 0.f;
         if (row < p.Sq) {
-            if (p.lse != nullptr && hi == 0 && dv0 == 0) {
+            if (p.lse != nullptr && hie == 0 && dv0 == 0) {
                 const float m_use = (m_run[qb] == -INFINITY) ? 0.f : m_run[qb];
-                p.lse[(int64_t)bh * p.Sq + row] = l_tot > 0.f ? (m_use + __builtin_log2f(l_tot)) * kLn2 : -INFINITY;
+                p.lse[(int64_t)bh * p.Sq + row] = l_tot > 0.f ? (m_use + __builtin_log2f(l_tot)) * kLn2 : -INFINITY;   // (row: from the opaque lane copy)
             }
             char* rp = obase + (int64_t)row * p.os[2] * 2;
 #pragma unroll
@@ -1067,7 +1088,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                     typename E::vec4 y = E::cvt4(x);
                     u32x2 raw;
                     __builtin_memcpy(&raw, &y, 8);
-                    gstore8(rp + ((dv0 + d) * 32 + 8 * g + 4 * hi) * 2, raw);
+                    gstore8(rp + ((dv0 + d) * 32 + 8 * g + 4 * hie) * 2, raw);
                 }
         }
     }

@@ -60,8 +60,10 @@ inline void ensure_smem(int smem) {
 inline int launch_rc() { return (t_launch_log != nullptr || hipGetLastError() == hipSuccess) ? 0 : -6; }
 
 constexpr bool mode_is_vec(int MODE) { return mode_is_vector(MODE); }
-constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB) {
-    return (RING == 2 ? 6 : 4) * KT * D * 2 + (mode_is_vec(MODE) ? NW * QB * 6144 : 0) + (mode_has_keypad(MODE) ? kFwdKpMaxTiles * 8 : 0);   // K/V buffers + per-wave bias / mask images + key-padding visibility words
+constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB, int BF32 = 0) {
+    // K/V buffers + per-wave bias / mask images (fp32 bias: 8 KiB instead of 4, and no mask area unless the mode has a mask operand) + key-padding visibility words
+    return (RING == 2 ? 6 : 4) * KT * D * 2 + (mode_is_vec(MODE) ? NW * QB * ((BF32 ? 8192 : 4096) + ((BF32 && !mode_has_vmask(MODE)) ? 0 : 2048)) : 0) +
+           (mode_has_keypad(MODE) ? kFwdKpMaxTiles * 8 : 0);
 }
 
 // one instantiation of the forward kernel: NW waves x QB 32-row blocks per wave, staging scheme RING, accumulator seeding SEED
@@ -73,12 +75,12 @@ inline bool pair_wanted(long blocks, long slots) { return g_pair_mode < 0 ? bloc
 #else
 inline bool pair_wanted(long blocks, long slots) { return blocks >= kPairRounds * slots; }
 #endif
-template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int RING = 0, int SEED = 0, int DROP = 0, int VH = 1>
+template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int RING = 0, int SEED = 0, int DROP = 0, int VH = 1, int FOLD = 0, int BF32 = 0>
 int launch_fwd_one(FwdParams p, hipStream_t s) {
     constexpr int BM = NW * QB * 32;
-    constexpr int smem = fwd_smem(D, RING, MODE, NW, QB);
+    constexpr int smem = fwd_smem(D, RING, MODE, NW, QB, BF32);
     p.nqblk = (p.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, 0, DROP, RING, 0, SEED, VH>;
+    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, 0, DROP, RING, 0, SEED, VH, FOLD, BF32>;
     ensure_smem<kern>(smem);
     // causal: pair block r with block nqblk-1-r in one workgroup (equal workgroups, see the kernel) when the single blocks fill the
     // chip's workgroup slots at least kPairRounds times; smaller launches keep single blocks, heaviest first

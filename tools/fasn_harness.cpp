@@ -80,7 +80,7 @@ struct Problem {
     int B, H, Sq, Sk, D, dtype, causal;
     float scale, n;
     int mask_kind;  // 0 none, 1 key-padding [B,1,1,Sk], 2 dense random [B,H,Sq,Sk], 3 key-padding layout with every key visible, 4 key-padding with bench.py's lengths
-    int bias_kind;  // 0 none, 1 alibi [H,Sq,Sk] same dtype, 2 random f32 [B,H,Sq,Sk]
+    int bias_kind;  // 0 none, 1 alibi [H,Sq,Sk] same dtype, 2 random f32 [B,H,Sq,Sk], 3 alibi [H,Sq,Sk] in fp32
     float std;
 };
 
@@ -125,6 +125,14 @@ static void make_inputs(const Problem& P, Host& h, uint64_t seed) {
                     h.bias16[((size_t)hh * P.Sq + i) * P.Sk + j] = enc(-slope * fabsf((float)(i + P.Sk - P.Sq - j)), P.dtype);
         }
         h.bs[0] = 0; h.bs[1] = (int64_t)P.Sq * P.Sk; h.bs[2] = P.Sk; h.bs[3] = 1;
+    } else if (P.bias_kind == 3) {
+        h.bias32.resize((size_t)P.H * P.Sq * P.Sk);
+        for (int hh = 0; hh < P.H; ++hh) {
+            float slope = powf(2.f, -8.f * (hh + 1) / P.H);
+            for (int i = 0; i < P.Sq; ++i)
+                for (int j = 0; j < P.Sk; ++j) h.bias32[((size_t)hh * P.Sq + i) * P.Sk + j] = -slope * fabsf((float)(i + P.Sk - P.Sq - j));
+        }
+        h.bs[0] = 0; h.bs[1] = (int64_t)P.Sq * P.Sk; h.bs[2] = P.Sk; h.bs[3] = 1;
     } else if (P.bias_kind == 2) {
         h.bias32.resize((size_t)P.B * P.H * P.Sq * P.Sk);
         for (auto& x : h.bias32) x = r.normal(1.0f);
@@ -159,7 +167,7 @@ static void reference_head(const Problem& P, const Host& h, int b, int hh, bool 
             s *= P.scale;
             bool show = !(P.causal && j > i + coff);
             if (P.bias_kind == 1) s += dec(h.bias16[hh * h.bs[1] + (size_t)i * h.bs[2] + j], P.dtype);
-            if (P.bias_kind == 2) s += h.bias32[b * h.bs[0] + hh * h.bs[1] + (size_t)i * h.bs[2] + j];
+            if (P.bias_kind >= 2) s += h.bias32[b * h.bs[0] + hh * h.bs[1] + (size_t)i * h.bs[2] + j];
             if (P.mask_kind) show = show && h.mask[b * h.ms[0] + hh * h.ms[1] + (size_t)i * h.ms[2] + j * h.ms[3]];
             x[j] = show ? s : -INFINITY;
             mx = std::max(mx, x[j]);
@@ -220,7 +228,7 @@ static void dev_alloc(const Problem& P, const Host& h, Dev& d) {
     d.v = upload(h.v);
     d.dout = upload(h.dout);
     d.mask = upload(h.mask);
-    d.bias = P.bias_kind == 2 ? upload(h.bias32) : upload(h.bias16);
+    d.bias = P.bias_kind >= 2 ? upload(h.bias32) : upload(h.bias16);
     HIP_CHECK(hipMalloc(&d.o, nq * 2));
     HIP_CHECK(hipMalloc(&d.dq, nq * 2));
     HIP_CHECK(hipMalloc(&d.dk, nk * 2));
@@ -262,7 +270,7 @@ static void fill_args(const Problem& P, const Host& h, Dev& d, fasn_bwd_args& a)
     if (P.bias_kind) {
         f.bias.ptr = d.bias;
         for (int i = 0; i < 4; ++i) f.bias.stride[i] = h.bs[i];
-        f.bias_dtype = P.bias_kind == 2 ? FASN_BIAS_F32 : FASN_BIAS_SAME;
+        f.bias_dtype = P.bias_kind >= 2 ? FASN_BIAS_F32 : FASN_BIAS_SAME;
     }
     f.dtype = P.dtype;
     f.B = P.B; f.H = P.H; f.Sq = P.Sq; f.Sk = P.Sk; f.D = P.D; f.Dv = P.D;
@@ -459,6 +467,11 @@ static int do_test(int variant, bool quick) {
         {"d128 bf16 alibi+keypad lengths 8/7/6/4 (4,8,1024) n.5 (length pairs, rotated second walk)", mk(4, 8, 1024, 1024, 128, BF, 0, 0.5f, 4, 1), true},
         {"d128 f16 alibi+keypad lengths (3,8,576x832) n1 (odd batch)", mk(3, 8, 576, 832, 128, HF, 0, 1.f, 4, 1), true},
         {"d64 f16 f32bias+mask causal n1", mk(1, 2, 130, 190, 64, HF, 1, 1.f, 2, 2), true},
+        {"d64 bf16 f32 bias (vector image) n1", mk(2, 4, 256, 320, 64, BF, 0, 1.f, 0, 2), true},
+        {"d64 f16 f32 bias + dense mask causal n.5 (vector image)", mk(1, 2, 200, 264, 64, HF, 1, 0.5f, 2, 2), true},
+        {"d64 bf16 f32 bias + key padding n1 (vector image + visibility bits)", mk(3, 2, 320, 448, 64, BF, 0, 1.f, 1, 2), true},
+        {"d32 bf16 f32 bias n1 (vector image)", mk(2, 2, 256, 256, 32, BF, 0, 1.f, 0, 2), true},
+        {"d64 bf16 f32 alibi [H,L,S] + key padding lengths n.5", mk(4, 8, 512, 512, 64, BF, 0, 0.5f, 4, 3), true},
         {"d64 bf16 scale.3 n4", mk(1, 1, 1024, 1152, 64, BF, 0, 4.f, 0, 0, 0.3f), true},
         {"d256 bf16 256x320 n.5", mk(1, 2, 256, 320, 256, BF, 0, 0.5f), true},
         {"d256 f16 257x129 causal n1", mk(1, 2, 257, 129, 256, HF, 1, 1.f), true},
