@@ -69,8 +69,9 @@ int check_view(const fasn_view4& v, bool required, int esize = 2) {
 // fp32 bias next to 16-bit q / k / v on the vector path (round 5): the head dims whose kernels have the fp32 image instantiation,
 // per pass (0 forward, 1 backward). Everything else keeps the element-load kernels for such a bias.
 bool f32_bias_vector(int D, int pass) {
-    (void)pass;   // (head dim 128: the two-wave backward kernels and the 8-wave forward have no room for 8 KiB images yet)
-    return D == 32 || D == 64;
+    (void)pass;   // (head dim 128: on the 4-wave forward and the one-wave backward kernels - the 8-wave forward and the two-wave backward kernels
+                  // have no LDS left for 8 KiB images; head dim 256: element loads)
+    return D == 32 || D == 64 || D == 128;
 }
 
 int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l, int pass = 0) {

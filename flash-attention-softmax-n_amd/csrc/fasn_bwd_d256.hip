@@ -24,7 +24,19 @@ static int launch_ws256(BwdParams p, hipStream_t s) {
         ensure_smem<kern>(smem);
         FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * nbh)), dim3(512), smem, s, p);
     }
-    {
+    if (p.f.kvg > 1) {   // grouped K/V (plain / causal): one workgroup per K/V head and key block walks the query heads of its group
+        constexpr int smem = bwd_ws256_smem_bytes();
+        p.nblk = (p.f.Sk + 127) / 128;
+        if (MODE == MODE_CAUSAL) {
+            constexpr auto kern = &fasn_bwd_dkdv_ws256_kernel<Tag, MODE_CAUSAL, 1>;
+            ensure_smem<kern>(smem);
+            FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(512), smem, s, p);
+        } else {
+            constexpr auto kern = &fasn_bwd_dkdv_ws256_kernel<Tag, MODE_PLAIN, 1>;
+            ensure_smem<kern>(smem);
+            FASN_LAUNCH(kern, dim3((unsigned)(p.nblk * (nbh / p.f.kvg))), dim3(512), smem, s, p);
+        }
+    } else {
         constexpr int smem = bwd_ws256_smem_bytes();
         p.nblk = (p.f.Sk + 127) / 128;
         if (MODE == MODE_CAUSAL || (MODE == MODE_KEYPAD && p.f.causal)) {
@@ -43,10 +55,10 @@ template <typename Tag>
 static int go(const BwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_BIAS_KEYPAD) mode = p.f.keypad_fallback;   // bias + key padding: the dense-mask view of the same mask
     if (p.f.drop_thr) return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL_SLOW, 1, 1, 1, 0, 2>(p, s);
-    if (p.f.kvg == 1 && !(FASN_BWD_VARIANT & 1)) {   // (developer library: bwd_variant bit 0 = the round-3 feature-half kernels, for A/B)
-        if (mode == MODE_PLAIN) return launch_ws256<Tag, MODE_PLAIN>(p, s);
+    if (!(FASN_BWD_VARIANT & 1)) {   // (developer library: bwd_variant bit 0 = the round-3 feature-half kernels, for A/B)
+        if (mode == MODE_PLAIN) return launch_ws256<Tag, MODE_PLAIN>(p, s);      // (grouped K/V included since round 5)
         if (mode == MODE_CAUSAL) return launch_ws256<Tag, MODE_CAUSAL>(p, s);
-        if (mode == MODE_KEYPAD && p.f.ms[3] == 1 && (p.f.Sk + 63) / 64 <= kDq256KpTiles) return launch_ws256<Tag, MODE_KEYPAD>(p, s);
+        if (p.f.kvg == 1 && mode == MODE_KEYPAD && p.f.ms[3] == 1 && (p.f.Sk + 63) / 64 <= kDq256KpTiles) return launch_ws256<Tag, MODE_KEYPAD>(p, s);
     }
     switch (mode) {
         case MODE_CAUSAL: return launch_bwd_one<Tag, 256, 1, 1, MODE_CAUSAL, 1, 1, 0, 0, 2>(p, s);

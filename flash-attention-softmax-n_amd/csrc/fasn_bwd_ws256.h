@@ -38,7 +38,11 @@ struct Unit256Dma {
 };
 
 // ------------------------------------------------------------------------------------------------------------------ dK, dV
-template <typename Tag, int MODE>
+// GQA = 1 (round 5; grouped-query attention, e.g. head dim 256 with 2 - 8 query heads per K/V head): one workgroup per K/V head and key block
+// walks the row units of ALL query heads of its group as one long sequence - the LDS-DMA rings, the P hand-over and the barriers do not
+// notice the seam between two heads, only the requests (Q / dO / statistics of head g) and the causal row index know about it - and dK / dV
+// of the K/V head leave the accumulators once: no per-query-head gradient buffer, no second pass (as fasn_bwd_dkdv_ws.h does at D = 128).
+template <typename Tag, int MODE, int GQA = 0>
 __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdParams bp) {
     static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL, "two-wave D = 256 backward: plain and causal");
     using E = ET<Tag>;
@@ -62,14 +66,16 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
     const int role = wave >> 2;    // 0 = A (S, P, dV), 1 = B (dP, dS, dK)
     const int kbw = wave & 3;
 
-    int bh, kblk;
-    block_to_work((int)blockIdx.x, p.B * p.H, bp.nblk, bh, kblk);
-    const int b = bh / p.H, h = bh % p.H;
+    const int G = GQA ? p.kvg : 1, HK = p.H / G;   // query heads per K/V head, K/V heads
+    int bhk, kblk;
+    block_to_work((int)blockIdx.x, p.B * HK, bp.nblk, bhk, kblk);
+    const int b = bhk / HK, hk = bhk % HK;
+    const int h = hk * G;   // first query head of the group (the only one without GQA)
     const int kw0 = kblk * BN + kbw * 32;
     const int key = kw0 + l31;
     const int coff = p.Sk - p.Sq;
-    const float* lsebase = p.lse + (int64_t)bh * p.Sq;
-    const float* dltbase = bp.delta + (int64_t)bh * p.Sq;
+    const float* lsebase = p.lse + ((int64_t)b * p.H + h) * p.Sq;      // of head h; head h + g: + g * Sq
+    const float* dltbase = bp.delta + ((int64_t)b * p.H + h) * p.Sq;
 
     const int nu_all = (p.Sq + RU - 1) / RU;
     int u0 = 0;
@@ -77,34 +83,48 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
         const int first_row = kblk * BN - coff;
         u0 = first_row <= 0 ? 0 : first_row / RU;
     }
-    const int nu = nu_all - u0;   // row units this workgroup walks (local index 0 .. nu-1 = rows 32 (u0 + u) ..)
+    const int nu1 = nu_all - u0;   // row units per query head (local index 0 .. nu1-1 = rows 32 (u0 + u) ..)
+    const int nu = G * nu1;        // row units this workgroup walks: head h, then h + 1, ... (step w = g * nu1 + u)
 
     Unit256Dma dq_, dd_;
     dq_.init(tid, p.qs[2]);
     dd_.init(tid, bp.dos[2]);
-    const u32x4 qrw = make_rsrc_words(p.q + (b * p.qs[0] + h * p.qs[1]) * 2, bp.qbytes);
-    const u32x4 drw = make_rsrc_words(bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2, bp.dobytes);
+    const char* const qhead0 = p.q + (b * p.qs[0] + h * p.qs[1]) * 2;
+    const char* const dhead0 = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2;
+    const u32x4 qrw0 = make_rsrc_words(qhead0, bp.qbytes), drw0 = make_rsrc_words(dhead0, bp.dobytes);
     const uint32_t ldsQ_w = lds_addr(ldsQ) + wave * 1024, ldsDO_w = lds_addr(ldsDO) + wave * 1024;
     // unit u: Q / dO images (2 + 2 requests per wave) and, by the first 32 threads of wave 4, its row statistics (negated: they are the
     // start values of the S / dP accumulators; rows past Sq get -inf: every weight of such a row is 0)
     float stL = 0.f, stX = 0.f;
     const int stid = tid - 256;
-    auto requests = [&](int u) {   // (units past the end read back as zeros: the request counts stay uniform)
-        const int uu = u < nu ? u0 + u : nu_all + 8;
-        dq_.dma(qrw, ldsQ_w + (u & 3) * B256_UNIT, uu * RU, p.qs[2]);
-        dd_.dma(drw, ldsDO_w + (u & 3) * B256_UNIT, uu * RU, bp.dos[2]);
+    // step w of the walk = unit u of query head h + g (w = g * nu1 + u); the three walkers below (requests, statistics, wave A's row
+    // index) each carry their own (g, u) counters, advanced with the step they serve
+    int rq_g = 0, rq_u = 0, st_g = 0, st_u = 0;
+    auto requests = [&](int w) {   // (steps past the end read back as zeros: the request counts stay uniform)
+        const int uu = __builtin_amdgcn_readfirstlane(w < nu ? u0 + rq_u : nu_all + 8);   // (provably uniform for the "s" operands of the DMA statements)
+        if constexpr (GQA) {   // the descriptors of head h + g (scalar arithmetic, two requests per tensor and wave)
+            const u32x4 qrw = make_rsrc_words(qhead0 + (int64_t)rq_g * p.qs[1] * 2, bp.qbytes), drw = make_rsrc_words(dhead0 + (int64_t)rq_g * bp.dos[1] * 2, bp.dobytes);
+            dq_.dma(qrw, ldsQ_w + (w & 3) * B256_UNIT, uu * RU, p.qs[2]);
+            dd_.dma(drw, ldsDO_w + (w & 3) * B256_UNIT, uu * RU, bp.dos[2]);
+            if (++rq_u == nu1) { rq_u = 0; if (rq_g + 1 < G) ++rq_g; }
+        } else {
+            dq_.dma(qrw0, ldsQ_w + (w & 3) * B256_UNIT, uu * RU, p.qs[2]);
+            dd_.dma(drw0, ldsDO_w + (w & 3) * B256_UNIT, uu * RU, bp.dos[2]);
+            ++rq_u;
+        }
     };
-    auto stats_gload = [&](int u) {
+    auto stats_gload = [&](int u) {   // u: the step (its statistics slot); the row comes from this walker's own (g, u)
         if (stid >= 0 && stid < RU) {
-            const int gr = (u0 + u) * RU + stid;
+            const int gr = (u0 + st_u) * RU + stid;
             float l = INFINITY, x = 0.f;
             if (u < nu && gr < p.Sq) {
-                l = lsebase[gr];
-                x = dltbase[gr];
+                l = lsebase[(int64_t)st_g * p.Sq + gr];
+                x = dltbase[(int64_t)st_g * p.Sq + gr];
             }
             stL = (l == -INFINITY || l == INFINITY) ? -INFINITY : -l * kLog2e;
             stX = -x;
         }
+        if (++st_u == nu1) { st_u = 0; if (st_g + 1 < G) ++st_g; }   // (uniform: every thread advances the walker)
     };
     auto stats_lstore = [&](int u) {
         if (stid >= 0 && stid < RU) {
@@ -117,8 +137,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
     vec8 opf[KS];
     {
         const bool ok = key < p.Sk;
-        const char* rp = (role == 0 ? p.k + (b * p.ks[0] + h * p.ks[1] + (int64_t)key * p.ks[2]) * 2
-                                    : p.v + (b * p.vs[0] + h * p.vs[1] + (int64_t)key * p.vs[2]) * 2) + hi * 16;
+        const char* rp = (role == 0 ? p.k + (b * p.ks[0] + hk * p.ks[1] + (int64_t)key * p.ks[2]) * 2
+                                    : p.v + (b * p.vs[0] + hk * p.vs[1] + (int64_t)key * p.vs[2]) * 2) + hi * 16;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             u32x4 a = {0u, 0u, 0u, 0u};
@@ -161,15 +181,17 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
     // its first visible row) are not skipped but masked like the diagonal itself, and a wave whose keys lie past Sk computes on zero
     // operands (its rows are never stored): no skip paths, the unit bodies stay straight-line (with them hipcc spilled 113 registers).
     auto needs_mask = [&](int u) { return causal && ((u0 + u) * RU + coff) < (kw0 + 31); };
+    int a_u = 0;   // wave A's unit index inside the current query head (step u of the walk = unit a_u of head u / nu1)
     auto unit_a = [&](const int u) {
-        const bool need_mask = needs_mask(u);
+        const bool need_mask = needs_mask(a_u);
         int ol = lane;   // an opaque copy of the lane id: the swizzled LDS addresses below are recomputed per unit instead of living in ~20
         asm volatile("" : "+v"(ol));   // registers across the loop next to 192 persistent ones (a spilled address comes back through scratch with a vmcnt wait)
         char* ps = pslot + (u & 1) * 8192;
         const char* tQ = ldsQ + (u & 3) * B256_UNIT;
         const char* tD = ldsDO + (u & 3) * B256_UNIT;
         const float* tL = ldsLse + (u & 3) * 32;
-        const int r0 = (u0 + u) * RU;
+        const int r0 = (u0 + a_u) * RU;
+        if (++a_u == nu1) a_u = 0;
         f32x16 sacc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -278,8 +300,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (key < p.Sk) {
-        char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + h * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 2
-                             : bp.dk + (b * bp.dks[0] + h * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
+        char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + hk * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 2
+                             : bp.dk + (b * bp.dks[0] + hk * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
         // key-padding launches (a mask over (batch, head, key), fasn_bwd_d256.hip) run this kernel unchanged: a hidden key's column of
         // scores touches nothing but its own dK / dV rows (LSE and delta already exclude it), so it is enough to write those as zeros
         const bool hidden = p.mask != nullptr && p.mask[b * p.ms[0] + h * p.ms[1] + key] == 0;
@@ -347,8 +369,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
     Unit256Dma dk_, dv_;
     dk_.init(tid, p.ks[2]);
     dv_.init(tid, p.vs[2]);
-    const u32x4 krw = make_rsrc_words(p.k + (b * p.ks[0] + h * p.ks[1]) * 2, p.kbytes);
-    const u32x4 vrw = make_rsrc_words(p.v + (b * p.vs[0] + h * p.vs[1]) * 2, p.vbytes);
+    const u32x4 krw = make_rsrc_words(p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2, p.kbytes);   // (grouped K/V: query head h reads K/V head h / kvg)
+    const u32x4 vrw = make_rsrc_words(p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2, p.vbytes);
     const uint32_t ldsK_w = lds_addr(ldsK) + wave * 1024, ldsV_w = lds_addr(ldsV) + wave * 1024;
     const int past = (p.Sk + KU - 1) / KU + 8;
     auto requests = [&](int u) {

@@ -181,7 +181,7 @@ def _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p):
                 _WARNED_SLOW.add(why)
                 import warnings
                 warnings.warn("flash_attention_n: this call takes the element-load kernels (3-5x slower than the vector path): "
-                              "a mask / bias whose rows are not aligned vectors (unaligned or strided rows; an fp32 bias with 16-bit q at head dims above 64, under dropout or with rows not 16-byte aligned), "
+                              "a mask / bias whose rows are not aligned vectors (unaligned or strided rows; an fp32 bias with 16-bit q at head dim 256, under dropout or with rows not 16-byte aligned), "
                               "scale <= 0 with a bias, fp16 with a very large scale, or dropout at head dim 256. "
                               "See fasn_fwd_path in include/fasn.h.", RuntimeWarning, stacklevel=4)
         c[key] = pl

@@ -273,7 +273,9 @@ def _xlnet_rel_attn_core(self, q_head, k_head_h, v_head_h, k_head_r, seg_mat=Non
         extra = bd + torch.einsum("ijbs,ibns->bnij", seg_mat, ef)
     visible = None
     if attn_mask is not None:          # [i, j, b, n] (n may be 1), 1 = masked
-        visible = torch.einsum("ijbn->bnij", attn_mask) == 0
+        # (contiguous: the comparison keeps the permuted memory order of its input, whose key stride is not 1 - such a mask takes the
+        # element-load kernels; [b, n or 1, i, j] with unit key stride takes the vector path, the head broadcast stays a stride 0)
+        visible = (torch.einsum("ijbn->bnij", attn_mask) == 0).contiguous()
     if output_attentions or head_mask is not None:
         # the probabilities themselves are wanted (or multiplied by head_mask, as transformers 4.x passes it and the reference's
         # rel_attn_core applies it, surgery_functions/_xlnet.py:66-67): the module's einsum route with the softmax_n row kernel

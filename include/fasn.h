@@ -140,8 +140,8 @@ int fasn_fwd(const fasn_fwd_args* args, fasn_stream_t stream);
  * Which kernel family `args` is routed to (ABI 4; the backward of the same call takes the same family): a non-negative
  * FASN_PATH_* value, or a negative FASN_E* code for arguments fasn_fwd would refuse. Every family gives the same results; they
  * differ in speed. FASN_PATH_ELEMENT is the one to know about: masks / biases whose rows cannot be moved in aligned vector
- * pieces (unaligned or strided rows, key stride != 1; an fp32 bias next to 16-bit q at head dims above 64, under dropout, or with rows
- * that are not 16-byte aligned - at head dims <= 64 an aligned fp32 bias takes the vector family since ABI 5), scale <= 0 with a bias, fp16 with
+ * pieces (unaligned or strided rows, key stride != 1; an fp32 bias next to 16-bit q at head dim 256, under dropout, or with rows
+ * that are not 16-byte aligned - at head dims <= 128 an aligned fp32 bias takes the vector family since ABI 5), scale <= 0 with a bias, fp16 with
  * scale*log2(e) > 8, and dropout at head dim 256 take per-element loads and run 3-5 x slower than the vector path. Nothing is launched. (The reference has no counterpart: its SDPA backends are picked inside torch.)
  */
 #define FASN_PATH_PLAIN 0       /* no mask / bias (causal or not) */

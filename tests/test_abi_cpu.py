@@ -150,11 +150,12 @@ def test_fwd_path_query(pkg):
     assert lib.fasn_fwd_path(with_views(mask=(64, 64, 8, 1))) == 2                                 # dense mask
     assert lib.fasn_fwd_path(with_views(bias=(0, 64, 8, 1), bias_dtype=1)) == 2                    # aligned 16-bit bias
     assert lib.fasn_fwd_path(with_views(mask=(8, 0, 0, 1), bias=(0, 64, 8, 1), bias_dtype=1)) == 3
-    # fp32 bias next to bf16 q (round 5): rows movable in 16-byte pieces take the vector path at head dims <= 64 (fp32 image instantiations),
-    # with a key-padding mask the visibility-bit family; head dim 128 / 256, 8-byte-only alignment and dropout keep the element loads
+    # fp32 bias next to bf16 q (round 5): rows movable in 16-byte pieces take the vector path at head dims <= 128 (fp32 image instantiations),
+    # with a key-padding mask the visibility-bit family; head dim 256, 8-byte-only alignment and dropout keep the element loads
     assert lib.fasn_fwd_path(with_views(bias=(0, 64, 8, 1), bias_dtype=2)) == 2
     assert lib.fasn_fwd_path(with_views(mask=(8, 0, 0, 1), bias=(0, 64, 8, 1), bias_dtype=2)) == 3
-    assert lib.fasn_fwd_path(with_views(bias=(0, 64, 8, 1), bias_dtype=2, D=128, Dv=128)) == 4
+    assert lib.fasn_fwd_path(with_views(bias=(0, 64, 8, 1), bias_dtype=2, D=128, Dv=128)) == 2
+    assert lib.fasn_fwd_path(with_views(bias=(0, 64, 8, 1), bias_dtype=2, D=256, Dv=256)) == 4
     assert lib.fasn_fwd_path(with_views(bias=(0, 60, 6, 1), bias_dtype=2)) == 4
     assert lib.fasn_fwd_path(with_views(bias=(0, 64, 8, 1), bias_dtype=2, dropout_p=0.1)) == 4
     assert lib.fasn_fwd_path(with_views(bias=(0, 64, 9, 1), bias_dtype=1)) == 4                    # unaligned bias rows

@@ -1531,3 +1531,33 @@ def test_grouped_query_attention(pkg, dev, kind, D, dtype):
         _check(got, want, dtype, f"gqa {kind} {nm}")
     with pytest.raises(ValueError):
         pkg.flash_attention_n(q, k[:, :1].expand(B, 3, S, D), v[:, :1].expand(B, 3, S, D))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape", [(2, 8, 2, 300, 420), (1, 8, 1, 512, 512), (2, 6, 3, 130, 700)])
+def test_grouped_query_attention_at_head_dim_256(pkg, dev, shape, causal, dtype):
+    """head dim 256 with grouped K/V (round 5): the two-wave backward kernels - dQ reads K/V head h // G, one dK/dV workgroup per K/V head
+    and key block walks the row units of all G query heads of its group as one sequence and writes dK / dV once (csrc/fasn_bwd_ws256.h).
+    Several key blocks per head, several row units per query head, L != S with the bottom-right causal alignment, G = 2, 4 and 8."""
+    B, H, Hkv, L, S = shape
+    D, G = 256, H // Hkv
+    q = _rand((B, H, L, D), dtype, dev, 11).requires_grad_()
+    k, v = (_rand((B, Hkv, S, D), dtype, dev, s).requires_grad_() for s in (12, 13))
+    do = _rand((B, H, L, D), dtype, dev, 14, std=1.0)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, is_causal=causal)
+    out.backward(do)
+    assert k.grad.shape == k.shape and v.grad.shape == v.shape
+    qc, kc, vc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v))
+    o = ref_attention_n(qc, kc.repeat_interleave(G, dim=1), vc.repeat_interleave(G, dim=1), softmax_n_param=0.5, is_causal=causal)
+    o.backward(do.cpu().float())
+    for got, want, nm in ((out, o, "out"), (q.grad, qc.grad, "dq"), (k.grad, kc.grad, "dk"), (v.grad, vc.grad, "dv")):
+        _check(got, want, dtype, f"gqa d256 causal={causal} {nm}")
+    import ctypes
+    a = pkg._lib.BwdArgs()   # ... and the launch table says so: the two-wave kernels, the dK/dV one in its grouped instantiation
+    kd = torch.empty_like(k)
+    pkg.flash_attn._fill_fwd(a.fwd, q.detach(), k.detach(), v.detach(), out.detach(), torch.empty(B, H, L, device=dev), None, None, 0.5, D ** -0.5, causal)
+    a.dout, a.dq, a.dk, a.dv = (pkg.flash_attn._view4(t) for t in (do, do, kd, kd))
+    a.delta = a.fwd.lse
+    names = [n for n, *_ in pkg._lib.launch_plan(a, pkg._lib.FASN_PLAN_BWD)]
+    assert any(n.startswith("fasn_bwd_dq_ws256_kernel") for n in names) and any(n.startswith("fasn_bwd_dkdv_ws256_kernel") and n.rstrip(">").endswith(", 1") for n in names), names

@@ -472,6 +472,9 @@ static int do_test(int variant, bool quick) {
         {"d64 bf16 f32 bias + key padding n1 (vector image + visibility bits)", mk(3, 2, 320, 448, 64, BF, 0, 1.f, 1, 2), true},
         {"d32 bf16 f32 bias n1 (vector image)", mk(2, 2, 256, 256, 32, BF, 0, 1.f, 0, 2), true},
         {"d64 bf16 f32 alibi [H,L,S] + key padding lengths n.5", mk(4, 8, 512, 512, 64, BF, 0, 0.5f, 4, 3), true},
+        {"d128 bf16 f32 alibi [H,L,S] + key padding lengths n.5 (4-wave forward, one-wave backward)", mk(4, 8, 384, 512, 128, BF, 0, 0.5f, 4, 3), true},
+        {"d128 f16 f32 bias + dense mask causal n1", mk(1, 2, 200, 264, 128, HF, 1, 1.f, 2, 2), true},
+        {"d128 bf16 f32 bias n0", mk(2, 2, 256, 320, 128, BF, 0, 0.f, 0, 2), true},
         {"d64 bf16 scale.3 n4", mk(1, 1, 1024, 1152, 64, BF, 0, 4.f, 0, 0, 0.3f), true},
         {"d256 bf16 256x320 n.5", mk(1, 2, 256, 320, 256, BF, 0, 0.5f), true},
         {"d256 f16 257x129 causal n1", mk(1, 2, 257, 129, 256, HF, 1, 1.f), true},
