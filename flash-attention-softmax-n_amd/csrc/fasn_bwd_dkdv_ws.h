@@ -67,6 +67,9 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     const int l31 = lane & 31;
     const int hi = lane >> 5;
     const int role = wave >> 2;    // 0 = A (S, P, dV), 1 = B (dP, dS, dK)
+#if FASN_PRIO_WS   // (round 5 A/B: static wave priority for one role of a SIMD's pair: 1 = wave B, 2 = wave A)
+    if (role == (FASN_PRIO_WS == 1 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
+#endif
     const int kbw = wave & 3;      // key block of this wave inside the workgroup's 128 keys
     const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
     static_assert(!(DROP && GQA), "dropout with grouped K/V stays on the one-wave kernel");
@@ -598,17 +601,7 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
                              : bp.dk + (b * bp.dks[0] + hk * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
         const float sc = role == 0 ? (DROP ? p.drop_scale : 1.0f) : bp.scale;
 #pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 x;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = acc[d][4 * g + e] * sc;
-                typename E::vec4 y = E::cvt4(x);
-                u32x2 raw;
-                __builtin_memcpy(&raw, &y, 8);
-                gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
-            }
+        for (int d = 0; d < DB; ++d) store_block_narrow<E>(rp + d * 64, acc[d], sc, hi);   // (8-byte stores: at its register limit, fasn_common.h)
     }
 }
 

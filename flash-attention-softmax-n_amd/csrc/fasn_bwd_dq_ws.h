@@ -56,6 +56,9 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     const int hi = lane >> 5;
     const int role = wave >> 2;   // 0 = A, 1 = B
     const int rbw = wave & 3;     // 32-row block of this wave inside the workgroup's 128 rows
+#if FASN_PRIO_WS   // (round 5 A/B: static wave priority for one role of a SIMD's pair: 1 = wave B (two of the three GEMMs), 2 = wave A (exponentials, bias))
+    if (role == (FASN_PRIO_WS == 1 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
+#endif
     const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
 
     // Ragged key-padded batch under a batch-broadcast bias (config 4): like the forward (fasn_fwd_kernel.h, kpair_plan) a workgroup takes
@@ -456,17 +459,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     if (role == 1 && row < p.Sq) {
         char* rp = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1] + (int64_t)row * bp.dqs[2]) * 2;
 #pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 x;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = acc[d][4 * g + e] * bp.scale;
-                typename E::vec4 y = E::cvt4(x);
-                u32x2 raw;
-                __builtin_memcpy(&raw, &y, 8);
-                gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
-            }
+        for (int d = 0; d < DB; ++d) store_block_wide<E>(rp + d * 64, acc[d], bp.scale, hi);   // 16-byte stores (round 5, fasn_common.h)
     }
     };   // item
     item(bh0, qi0, std::false_type{});

@@ -555,17 +555,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         if (row < p.Sq) {
             char* rp = dqbase + (int64_t)row * bp.dqs[2] * 2;
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 x;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = dqacc[qb][d][4 * g + e] * bp.scale;
-                    typename E::vec4 y = E::cvt4(x);
-                    u32x2 raw;
-                    __builtin_memcpy(&raw, &y, 8);
-                    gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
-                }
+            for (int d = 0; d < DB; ++d) store_block_narrow<E>(rp + d * 64, dqacc[qb][d], bp.scale, hi);   // (8-byte stores: several instantiations at their register limit, fasn_common.h)
         }
     }
     }   // pass
@@ -1030,22 +1020,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             char* rk = dkbase + (int64_t)key * bp.dks[2] * 2;
             char* rv = dvbase + (int64_t)key * bp.dvs[2] * 2;
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 x, y;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x[e] = dkacc[kb][d][4 * g + e] * bp.scale;
-                        y[e] = dvacc[kb][d][4 * g + e];
-                    }
-                    typename E::vec4 xk = E::cvt4(x), yv = E::cvt4(y);
-                    u32x2 ra, rb;
-                    __builtin_memcpy(&ra, &xk, 8);
-                    __builtin_memcpy(&rb, &yv, 8);
-                    gstore8(rk + ((d0 + d) * 32 + 8 * g + 4 * hi) * 2, ra);
-                    gstore8(rv + ((d0 + d) * 32 + 8 * g + 4 * hi) * 2, rb);
-                }
+            for (int d = 0; d < DB; ++d) {   // (8-byte stores: several instantiations at their register limit, fasn_common.h)
+                store_block_narrow<E>(rk + (d0 + d) * 64, dkacc[kb][d], bp.scale, hi);
+                store_block_narrow<E>(rv + (d0 + d) * 64, dvacc[kb][d], 1.0f, hi);
+            }
         }
     }
     }   // pass

@@ -360,22 +360,10 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
         char* rk = dkbase + (int64_t)key * bp.dks[2] * 2;
         char* rv = dvbase + (int64_t)key * bp.dvs[2] * 2;
 #pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 x, y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    x[e] = dkacc[d][4 * g + e] * bp.scale;
-                    y[e] = DROP ? dvacc[d][4 * g + e] * p.drop_scale : dvacc[d][4 * g + e];
-                }
-                typename E::vec4 xk = E::cvt4(x), yv = E::cvt4(y);
-                u32x2 ra, rb;
-                __builtin_memcpy(&ra, &xk, 8);
-                __builtin_memcpy(&rb, &yv, 8);
-                gstore8(rk + (d * 32 + 8 * g + 4 * hi) * 2, ra);
-                gstore8(rv + (d * 32 + 8 * g + 4 * hi) * 2, rb);
-            }
+        for (int d = 0; d < DB; ++d) {   // 16-byte stores (round 5, store_block_wide in fasn_common.h)
+            store_block_wide<E>(rk + d * 64, dkacc[d], bp.scale, hi);
+            store_block_wide<E>(rv + d * 64, dvacc[d], DROP ? p.drop_scale : 1.0f, hi);
+        }
     }
     }   // pass
 }
@@ -740,22 +728,10 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dkdv_pipe2_kernel(const BwdPa
             char* rk = dkbase + (int64_t)key * bp.dks[2] * 2;
             char* rv = dvbase + (int64_t)key * bp.dvs[2] * 2;
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 x, y;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x[e] = dkacc[kb][d][4 * g + e] * bp.scale;
-                        y[e] = dvacc[kb][d][4 * g + e];
-                    }
-                    typename E::vec4 xk = E::cvt4(x), yv = E::cvt4(y);
-                    u32x2 ra, rb;
-                    __builtin_memcpy(&ra, &xk, 8);
-                    __builtin_memcpy(&rb, &yv, 8);
-                    gstore8(rk + (d * 32 + 8 * g + 4 * hi) * 2, ra);
-                    gstore8(rv + (d * 32 + 8 * g + 4 * hi) * 2, rb);
-                }
+            for (int d = 0; d < DB; ++d) {
+                store_block_wide<E>(rk + d * 64, dkacc[kb][d], bp.scale, hi);
+                store_block_wide<E>(rv + d * 64, dvacc[kb][d], 1.0f, hi);
+            }
         }
     }
     }   // pass
@@ -1026,17 +1002,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
     if (row < p.Sq) {
         char* rp = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1] + (int64_t)row * bp.dqs[2]) * 2;
 #pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 x;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = dqacc[d][4 * g + e] * bp.scale;
-                typename E::vec4 y = E::cvt4(x);
-                u32x2 raw;
-                __builtin_memcpy(&raw, &y, 8);
-                gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
-            }
+        for (int d = 0; d < DB; ++d) store_block_wide<E>(rp + d * 64, dqacc[d], bp.scale, hi);   // 16-byte stores (round 5, fasn_common.h)
     }
     }   // pass
 }

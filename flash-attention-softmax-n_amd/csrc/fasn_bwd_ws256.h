@@ -77,6 +77,21 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
     const float* lsebase = p.lse + ((int64_t)b * p.H + h) * p.Sq;      // of head h; head h + g: + g * Sq
     const float* dltbase = bp.delta + ((int64_t)b * p.H + h) * p.Sq;
 
+    // key-padding launches (a mask pointer next to the plain / causal kernel, fasn_bwd_d256.hip): a key block whose 128 keys are all hidden
+    // has nothing to accumulate - its dK / dV rows are zeros - so the workgroup writes them and leaves before any operand is fetched
+    // (round 4 walked every row unit of such a block and zeroed the result at the store)
+    if (!GQA && p.mask != nullptr) {
+        const bool vis = key < p.Sk && p.mask[b * p.ms[0] + h * p.ms[1] + key] != 0;
+        if (!__syncthreads_or(vis ? 1 : 0)) {
+            if (key < p.Sk) {
+                char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + hk * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 2
+                                     : bp.dk + (b * bp.dks[0] + hk * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
+#pragma unroll
+                for (int c = 0; c < D / 8 / 2; ++c) gstore16(rp + (2 * c + hi) * 16, u32x4{0u, 0u, 0u, 0u});
+            }
+            return;
+        }
+    }
     const int nu_all = (p.Sq + RU - 1) / RU;
     int u0 = 0;
     if (causal) {
@@ -306,18 +321,13 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
         // scores touches nothing but its own dK / dV rows (LSE and delta already exclude it), so it is enough to write those as zeros
         const bool hidden = p.mask != nullptr && p.mask[b * p.ms[0] + h * p.ms[1] + key] == 0;
         const float sc = hidden ? 0.f : (role == 0 ? 1.0f : bp.scale);
+        if (hidden) {   // (a hidden column may hold inf / NaN: zeros are written, not 0 * acc; both lanes of a key share the flag)
 #pragma unroll
-        for (int d = 0; d < DB; ++d)
+            for (int c = 0; c < D / 8 / 2; ++c) gstore16(rp + (2 * c + hi) * 16, u32x4{0u, 0u, 0u, 0u});
+        } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 x;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = hidden ? 0.f : acc[d][4 * g + e] * sc;   // (a hidden column may hold inf / NaN)
-                typename E::vec4 y = E::cvt4(x);
-                u32x2 raw;
-                __builtin_memcpy(&raw, &y, 8);
-                gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
-            }
+            for (int d = 0; d < DB; ++d) store_block_wide<E>(rp + d * 64, acc[d], sc, hi);   // 16-byte stores (round 5, fasn_common.h)
+        }
     }
 }
 
@@ -568,16 +578,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
             char* rp = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1] + (int64_t)row * bp.dqs[2]) * 2;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 x;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = acc[d][4 * g + e] * bp.scale;
-                    typename E::vec4 y = E::cvt4(x);
-                    u32x2 raw;
-                    __builtin_memcpy(&raw, &y, 8);
-                    gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
-                }
+                store_block_wide<E>(rp + d * 64, acc[d], bp.scale, hi);   // 16-byte stores (round 5, fasn_common.h)
         }
     }
 }

@@ -4,6 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef FASN_PRIO8
+#define FASN_PRIO8 0   // (round 5 A/B: static s_setprio 1 for the second-dispatched half of the 8-wave forward workgroups, cdna_hip_programming.md T5 static form)
+#endif
+#ifndef FASN_PRIO_WS
+#define FASN_PRIO_WS 0   // (round 5 A/B, two-wave backward kernels: static s_setprio 1 for wave B (1) or wave A (2) of every SIMD's pair)
+#endif
+
 namespace fasn {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -263,6 +270,46 @@ FASN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 FASN_DEV u32x4 gload16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 FASN_DEV void gstore16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 FASN_DEV void gstore8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
+
+// One 32-column block of a row-per-lane result (accumulator registers 4g .. 4g+3 = columns 8g + 4hi .. + 3 of the lane's row; the partner
+// lane in the other half-wave holds the other four of every eight): scaled, rounded to the element type and written as TWO 16-byte stores
+// per lane instead of four 8-byte ones - groups (g, g+1) are paired through v_permlane32_swap, after which the lower half-wave holds
+// columns 8g .. 8g+7 and the upper one 8(g+1) .. 8(g+1)+7. The store tail of a row-per-lane epilogue is bound by instruction issue
+// (cdna_hip_programming.md T21). `blk` = the row's address + the block's column offset; both half-waves must be active for the row.
+template <typename E>
+FASN_DEV void store_block_wide(char* blk, const f32x16& acc, float sc, int hi) {
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+        u32x2 pk[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = acc[4 * (g + j) + e] * sc;
+            typename E::vec4 y = E::cvt4(x);
+            __builtin_memcpy(&pk[j], &y, 8);
+        }
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+        gstore16(blk + (8 * g + 8 * hi) * 2, u32x4{r0[0], r1[0], r0[1], r1[1]});
+    }
+}
+
+// the same block as four 8-byte stores per lane: for the kernels that sit at their register limit (the paired form holds two groups at a
+// time and cost them 1 - 13 spilled registers in the epilogue)
+template <typename E>
+FASN_DEV void store_block_narrow(char* blk, const f32x16& acc, float sc, int hi) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = acc[4 * g + e] * sc;
+        typename E::vec4 y = E::cvt4(x);
+        u32x2 raw;
+        __builtin_memcpy(&raw, &y, 8);
+        gstore8(blk + (8 * g + 4 * hi) * 2, raw);
+    }
+}
 
 // XCD-aware block -> (batch*head, q-block) map. Blocks are dispatched round-robin over the 8 XCDs
 // (block b -> XCD b%8, observed, used for speed only): give every XCD whole heads so one head's

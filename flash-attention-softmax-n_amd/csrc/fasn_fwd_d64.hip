@@ -90,11 +90,10 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (l.variant != 0) return dev_variant<Tag>(p, l, s);
 #endif
     if (big_plain) return launch_fwd_cfg<Tag, 64, 2, 2, 4, 2, 2>(p, l.mode, s);
-    // causal launches of many rounds (or of long blocks) at the plain kernel's tuning point with the folded two-phase walk (round 5; same box,
-    // profiles/r05_causal_forward_folded_two_phase_ab.log: C5 2.28 -> 2.23 ms, (4,32,8192,64) 1.056 -> 1.038, (2,16,16384,64) 1.030 -> 0.992;
-    // at two rounds of 4096-key blocks - C3 - the 32-row kernel's finer workgroups still win: 0.310 against 0.318 ms)
-    if (l.mode == MODE_CAUSAL && p.Sq >= 256 && (blocks_qb2 >= 4096 || (blocks_qb2 >= 2048 && p.Sq >= 8192)))
-        return launch_fwd_one<Tag, 64, 2, MODE_CAUSAL, 2, 4, 2, 2, 0, 1, 1>(p, s);
+    // causal launches of at least two rounds at the plain kernel's tuning point with the folded two-phase walk (round 5; same box, final builds,
+    // three alternations - profiles/r05_causal_forward_folded_two_phase_ab.log: C5 2.377 -> 2.362 ms, (16,16,4096,64) 0.6325 -> 0.6246, (4,32,8192,64)
+    // 1.115 -> 1.085, (2,16,16384,64) 1.072 -> 1.017, C3 (fp16, two rounds) 0.3446 -> 0.3409; on other boxes C5 +2.1 %, C3 +0.3 .. +1.0 %)
+    if (l.mode == MODE_CAUSAL && p.Sq >= 256 && blocks_qb2 >= 2048) return launch_fwd_one<Tag, 64, 2, MODE_CAUSAL, 2, 4, 2, 2, 0, 1, 1>(p, s);
     return launch_fwd_cfg<Tag, 64, 1, 3, 4, 2, 2>(p, l.mode, s);
 }
 int launch_fwd_d64(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {

@@ -1078,18 +1078,13 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                 p.lse[(int64_t)bh * p.Sq + row] = l_tot > 0.f ? (m_use + __builtin_log2f(l_tot)) * kLn2 : -INFINITY;   // (row: from the opaque lane copy)
             }
             char* rp = obase + (int64_t)row * p.os[2] * 2;
+            // 16-byte stores (round 5, store_block_wide in fasn_common.h: half the store instructions of the row-per-lane epilogue;
+            // same box: M0 0.4953 -> 0.4872 ms, C2 0.0437 -> 0.0414, C3 0.3032 -> 0.2989, C5 2.321 -> 2.272; profiles/r05_wide_output_stores_ab.log)
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 x;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = oacc[qb][d][4 * g + e] * inv;
-                    typename E::vec4 y = E::cvt4(x);
-                    u32x2 raw;
-                    __builtin_memcpy(&raw, &y, 8);
-                    gstore8(rp + ((dv0 + d) * 32 + 8 * g + 4 * hie) * 2, raw);
-                }
+            for (int d = 0; d < DB; ++d) {
+                if constexpr (D == 32 && DROP) store_block_narrow<E>(rp + (dv0 + d) * 64, oacc[qb][d], inv, hie);   // (at their register limit)
+                else store_block_wide<E>(rp + (dv0 + d) * 64, oacc[qb][d], inv, hie);
+            }
         }
     }
 #ifdef FASN_DEV_VARIANTS

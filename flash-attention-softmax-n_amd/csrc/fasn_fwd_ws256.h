@@ -286,17 +286,7 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
             const float inv = aslot[0];
             char* rp = p.o + (b * p.os[0] + h * p.os[1] + (int64_t)row * p.os[2]) * 2;
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 x;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = oacc[d][4 * g + e] * inv;
-                    typename E::vec4 y = E::cvt4(x);
-                    u32x2 raw;
-                    __builtin_memcpy(&raw, &y, 8);
-                    gstore8(rp + (d * 32 + 8 * g + 4 * hi) * 2, raw);
-                }
+            for (int d = 0; d < DB; ++d) store_block_wide<E>(rp + d * 64, oacc[d], inv, hi);   // 16-byte stores (round 5, fasn_common.h)
         }
     }
 }

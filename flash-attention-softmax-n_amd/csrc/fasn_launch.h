@@ -80,7 +80,7 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
     constexpr int BM = NW * QB * 32;
     constexpr int smem = fwd_smem(D, RING, MODE, NW, QB, BF32);
     p.nqblk = (p.Sq + BM - 1) / BM;
-    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, 0, DROP, RING, 0, SEED, VH, FOLD, BF32>;
+    constexpr auto kern = &fasn_fwd_kernel<Tag, D, QB, MODE, OCC, NW, (NW == 8 ? FASN_PRIO8 : 0), DROP, RING, 0, SEED, VH, FOLD, BF32>;
     ensure_smem<kern>(smem);
     // causal: pair block r with block nqblk-1-r in one workgroup (equal workgroups, see the kernel) when the single blocks fill the
     // chip's workgroup slots at least kPairRounds times; smaller launches keep single blocks, heaviest first

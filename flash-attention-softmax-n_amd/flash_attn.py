@@ -392,6 +392,13 @@ def _prepare(query, key, value, n, scale, dropout_p, mask, bias):
         # a bias that needs a gradient and broadcasts over batch and / or heads only ([H,L,S], [1,H,L,S], [B,1,L,S], [1,1,L,S]) keeps
         # its own shape: fasn_bwd then returns the gradient already summed over those dimensions (csrc/fasn_bwd_dbias.h).
         # (L == 1 stays on the dense path: a one-row bias is also a ROW broadcast, whose stride 0 the reduced form rejects)
+        # Round 5: a bias that ALSO broadcasts over rows ([1,H,1,S], [B,1,1,S], [1,1,1,S] - per-key biases) is expanded over the rows as a
+        # view (row stride 0: the kernels read one row) and takes the same reduced form: the kernel sums over batch / heads into a
+        # [1 or B, 1 or H, L, S] buffer and the expand's own backward sums that over the rows - 1/B or 1/H of the dense [B,H,L,S] dS buffer
+        # round 4 wrote for these shapes. (The sum over rows inside the kernel would be a column sum of dS in the dK/dV kernels: not built.)
+        if (bias.requires_grad and torch.is_grad_enabled() and L > 1 and bias.shape[2] == 1 and bias.shape[3] == S
+                and bias.shape[0] in (1, B) and bias.shape[1] in (1, H)):
+            bias = bias.expand(bias.shape[0], bias.shape[1], L, S)
         bias_small = (bias.requires_grad and torch.is_grad_enabled() and dropout_p == 0.0 and query.dtype != torch.float32
                       and L > 1 and bias.shape[2] == L and bias.shape[3] == S and bias.shape[0] in (1, B) and bias.shape[1] in (1, H)
                       and ((bias.shape[0] == 1 and B > 1) or (bias.shape[1] == 1 and H > 1)) and bias.stride(3) == 1)

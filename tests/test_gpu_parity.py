@@ -1223,6 +1223,33 @@ def test_attn_bias_gradient_reduced_in_kernel(pkg, dev, kind, D, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", ["1h1s", "b11s", "111s", "h1s"])
+def test_attn_bias_gradient_of_a_per_key_bias(pkg, dev, shape, dtype):
+    """A differentiable bias that broadcasts over ROWS as well ([1,H,1,S], [B,1,1,S], [1,1,1,S]: per-key biases) with L > 1 (round 5): the
+    front end expands it over the rows as a stride-0 view, the kernel reduces over batch / heads into a [1 or B, 1 or H, L, S] buffer and
+    the expand's backward sums the rows - no dense [B,H,L,S] dS buffer (round 4 wrote one for these shapes)."""
+    B, H, L, S, D = 4, 4, 384, 512, 64
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    bshape = {"1h1s": (1, H, 1, S), "b11s": (B, 1, 1, S), "111s": (1, 1, 1, S), "h1s": (H, 1, S)}[shape]
+    bias = torch.randn(*bshape, generator=torch.Generator().manual_seed(5)).to(dtype).to(dev).requires_grad_()
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, attn_bias=bias)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out.backward(do)
+    extra = torch.cuda.max_memory_allocated() - base
+    dense = B * H * L * S * q.element_size()
+    assert extra <= dense // 2 + 6 * q.numel() * q.element_size() + (1 << 20), f"backward peaked {extra} bytes above the forward state: a dense dS buffer is {dense}"
+    assert bias.grad is not None and bias.grad.shape == bias.shape and bias.grad.dtype == bias.dtype
+    qc, kc, vc, bc = (t.detach().cpu().float().requires_grad_() for t in (q, k, v, bias))
+    o = ref_attention_n(qc, kc, vc, softmax_n_param=1.0, attn_bias=bc)
+    o.backward(do.cpu().float())
+    for got, want, nm in ((out, o, "out"), (q.grad, qc.grad, "dq"), (k.grad, kc.grad, "dk"), (v.grad, vc.grad, "dv"), (bias.grad, bc.grad, "dbias")):
+        _check(got, want, dtype, f"{shape}/{nm}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("kind", ["hls", "hls+causal", "hls+keypad", "11ls+keypad+causal", "b1ls"])
 def test_attn_bias_gradient_with_more_tiles_than_workgroups(pkg, dev, kind, D, dtype):
