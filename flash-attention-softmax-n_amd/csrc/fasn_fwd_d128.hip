@@ -1,6 +1,9 @@
 // D = 128 forward instantiations (QB=1: 32 query rows per wave; O^T alone is 64 registers).
 // A/B tuning points and ablations: FASN_DEV_VARIANTS builds only (tools/libfasn_dev.so), see fasn_launch.h.
 #include "fasn_launch.h"
+#ifndef FASN_BF32_4WAVE
+#define FASN_BF32_4WAVE 0   // (round 5 A/B: the first fp32-bias forward at D = 128 - 4 waves, one workgroup per CU - instead of the 8-wave register-staged one)
+#endif
 namespace fasn {
 template <typename Tag>
 static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
@@ -13,13 +16,26 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         }
     }
 #endif
-    if (p.bias_f32) {   // fp32 bias next to 16-bit q / k / v: the fp32 image instantiations on the 4-wave kernel (8 KiB images for eight waves do not fit next to three K/V buffers)
+    if (p.bias_f32) {
+        // fp32 bias next to 16-bit q / k / v: the fp32 image instantiations. Eight 8 KiB images do not fit next to the three K/V buffers of the
+        // direct-to-LDS ring (160 KiB + the visibility words), but they do next to the TWO buffers of the register-staged ring (64 + 64 KiB):
+        // the 8-wave workgroup with RING = 0 (round 5; 242 - 256 registers, no spill). FASN_BF32_4WAVE=1: the first build (4 waves, one
+        // workgroup per CU, direct-to-LDS), for A/B.
+#if FASN_BF32_4WAVE
         switch (l.mode) {
             case MODE_GENERAL: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 1, 4, 2, 2, 0, 1, 0, 1>(p, s);
             case MODE_GENERAL_B: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_B, 1, 4, 2, 2, 0, 1, 0, 1>(p, s);
             case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 128, 1, MODE_BIAS_KEYPAD, 1, 4, 2, 2, 0, 1, 0, 1>(p, s);
             default: break;
         }
+#else
+        switch (l.mode) {
+            case MODE_GENERAL: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 0, 2, 0, 1, 0, 1>(p, s);
+            case MODE_GENERAL_B: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL_B, 2, 8, 0, 2, 0, 1, 0, 1>(p, s);
+            case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 128, 1, MODE_BIAS_KEYPAD, 2, 8, 0, 2, 0, 1, 0, 1>(p, s);
+            default: break;
+        }
+#endif
     }
     switch (l.mode) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 128, 1, MODE_GENERAL, 2, 8, 2, 2>(p, s);
