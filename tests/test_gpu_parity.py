@@ -400,17 +400,20 @@ def test_mask_bias_combinations(pkg, dev, kind, D, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("D", [32, 64, 128])
-@pytest.mark.parametrize("with_mask", [False, True])
+@pytest.mark.parametrize("with_mask", [False, True, "dense"])
 def test_fp32_bias_next_to_16_bit_inputs(pkg, dev, with_mask, D, dtype):
     """An fp32 additive bias next to fp16 / bf16 q / k / v (what Hugging Face models hand over; the reference adds the mask in whatever dtype
     SDPA is given, core/flash_attn.py:100-113) on the vector path (round 5): fp32 images in the forward (D = 128: the 8-wave register-staged
     kernel) and the one-wave dQ kernel, the fp32 bias ring of the two-wave dK/dV kernel at D = 128 (one-wave elsewhere). Several key blocks and
     row blocks, ragged ends, a head-broadcast [H,L,S] ALiBi with values a 16-bit bias could not hold next to a key-padding mask."""
-    B, H, L, S = 3, 4, 300, 424
+    B, H, L, S = 3, 4, 300, 432
     q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
     do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
     bias = synth.alibi_bias(H, L, S, torch.float32, device=dev) + 1e-3 * torch.randn(H, L, S, generator=torch.Generator().manual_seed(9)).to(dev)
     mask = synth.keypad_mask(B, S, device=dev) if with_mask else None
+    if with_mask == "dense":   # a per-(batch, row) boolean mask with aligned rows: the mask image next to the fp32 bias image
+        mask = (torch.rand(B, 1, L, S, generator=torch.Generator().manual_seed(5)) < 0.8).to(dev)
+        mask[..., 0] = True
     from flash_attention_softmax_n_amd.flash_attn import kernel_path
     assert kernel_path(q, k, v, attn_mask=mask, attn_bias=bias) in ("vector mask/bias", "vector bias + key-padding")
     out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, attn_mask=mask, attn_bias=bias)
