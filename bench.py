@@ -10,7 +10,7 @@ Either way WORLD_SIZE must equal --gpus and N GPUs must be visible, or the run F
 
 A step = one pass of the hot path over the whole batch, inputs resident in HBM:
   --pass fwd     one flash_attention_n forward (Python front end -> ctypes -> fasn_fwd)                     [default, the metric]
-  --pass fwdbwd  forward + backward through autograd (fasn_fwd, then fasn_bwd = delta + dQ + dK/dV kernels)
+  --pass fwdbwd  forward + backward through autograd (fasn_fwd, then fasn_bwd = [delta +] dQ + dK/dV kernels)
   --pass bwd     the backward alone: one fasn_bwd call on saved (o, lse) with preallocated gradients
 Rank 0 prints ONE JSON line; `value` = whole-job steps/s = N * K / max-over-ranks(wall time of K steps).
 In the line: `roofline` (dominant kernel(s) vs the dense MFMA peak, duration from events on the launch stream, HBM traffic
@@ -304,7 +304,7 @@ def main():
             o = pkg.flash_attention_n(qg, kg, vg, softmax_n_param=n, is_causal=causal, attn_mask=mask, attn_bias=bias)
             o.backward(do)
 
-        # the backward alone: one fasn_bwd (delta + dQ + dK/dV) on the saved forward state, gradients preallocated
+        # the backward alone: one fasn_bwd ([delta +] dQ + dK/dV) on the saved forward state, gradients preallocated
         o_s = torch.empty_like(q)
         lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
         m8 = None if mask is None else mask.expand(B, H, S, S).view(torch.uint8)

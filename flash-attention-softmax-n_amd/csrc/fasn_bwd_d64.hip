@@ -2,6 +2,9 @@
 // (the two-wave kernels of D = 128 measured slower here: (8,16,4096,64) backward 2.18 ms against 1.81 ms - at D = 64 the one-wave
 // kernels already run two waves per SIMD and the exponentials, not registers, are the limit)
 #include "fasn_bwd_launch.h"
+#ifndef FASN_DELTA_KERNEL
+#define FASN_DELTA_KERNEL 0   // (round 5 A/B: 1 = keep the separate delta launch in front of the pipelined kernels)
+#endif
 namespace fasn {
 #ifdef FASN_DEV_VARIANTS
 int launch_bwd_d64_exp(const BwdParams& p, int which, hipStream_t s);
@@ -21,6 +24,9 @@ int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s) {
     const bool pipe_ok = (l.mode == MODE_PLAIN || l.mode == MODE_CAUSAL) && p.f.kvg == 1;   // (with or without dropout)
     if (pipe_ok && !(FASN_BWD_VARIANT & 64)) q.skip |= 1;
     if (pipe_ok && !(FASN_BWD_VARIANT & 128)) q.skip |= 2;
+    // both pipelined kernels: no delta launch either - the dQ kernel, which runs first, computes delta = rowsum(O o dO) of its rows in its prologue
+    // (bit-identical to fasn_bwd_delta_kernel) and stores it for the dK/dV kernel (C2 backward -7 %, the other D = 64 configs -1.5 .. -2.5 %)
+    if (q.skip == 3 && !FASN_DELTA_KERNEL) q.skip |= 4;
     int rc = l.dtype == 1 ? launch_bwd_mode<bf16_tag, 64, 1, 1, 2, 2>(q, l.mode, s) : launch_bwd_mode<f16_tag, 64, 1, 1, 2, 2>(q, l.mode, s);
     if (rc) return rc;
     if (q.skip & 2) rc = launch_bwd_dq_pipe_d64(p, l, s);

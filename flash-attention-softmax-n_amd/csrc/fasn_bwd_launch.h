@@ -34,7 +34,7 @@ template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, i
 int launch_bwd_one(BwdParams p, hipStream_t s) {
     static_assert(!BF32 || (WS == 0 && DROP == 0 && DH == 1), "fp32 bias image: one-wave kernels without dropout");
     const int nbh = p.f.B * p.f.H;
-    {   // delta
+    if (!(p.skip & 4)) {   // delta (skip bit 2: the pipelined D = 64 dQ kernel computes and publishes it itself, round 5)
         constexpr int RPB = 256 / (D / 8);
         const int64_t rows = (int64_t)nbh * p.f.Sq;
         FASN_LAUNCH((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);

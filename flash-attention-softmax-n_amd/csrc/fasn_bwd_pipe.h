@@ -747,6 +747,29 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dkdv_pipe2_kernel(const BwdPa
 // diagonal and the ragged last key tile zero hidden P in a small wave-uniform branch between B and A.
 constexpr int pipe_dq_smem_bytes() { return 2 * PNB * KT * 64 * 2; }
 
+// delta of a lane's row from the row's O and dO chunks (round 5: the dQ kernel computes delta = rowsum(O o dO) itself, in its prologue, and
+// publishes it for the dK/dV kernel that follows - fasn_bwd_delta_kernel is not launched on this path). The lane (row l31, half hi) holds the
+// 16-byte chunks 2s + hi (s = 0..3) of its row; the value is BIT-IDENTICAL to the delta kernel's: eight sequential fmas per chunk, then
+// the kernel's xor-1 / xor-2 / xor-4 tree over the eight chunk sums ((c0+c1) + (c2+c3)) + ((c4+c5) + (c6+c7)).
+template <typename E>
+FASN_DEV float row_delta_d64(const u32x4 (&o)[4], const u32x4 (&d)[4]) {
+    float c[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            acc += E::to_f32((uint16_t)(o[s][w] & 0xffff)) * E::to_f32((uint16_t)(d[s][w] & 0xffff));
+            acc += E::to_f32((uint16_t)(o[s][w] >> 16)) * E::to_f32((uint16_t)(d[s][w] >> 16));
+        }
+        c[s] = acc;
+    }
+    float pr[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) pr[s] = c[s] + __shfl_xor(c[s], 32);   // chunk 2s + chunk 2s+1
+    return (pr[0] + pr[1]) + (pr[2] + pr[3]);
+}
+
 // DROP = 1: the keep bits are drawn with the exponentials (a lane owns a row: one hash state per key quad, as in the forward) and kept
 // as the SIGN of P until the products; dP starts at 0: dS = |P| o ((kept ? dP / (1-p) : 0) - delta).
 template <typename Tag, int MODE, int DROP = 0>
@@ -805,27 +828,47 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[d][r] = 0.f;
 
+    // delta = rowsum(O o dO) of the lane's row: computed here (row_delta_d64) and published for the dK/dV kernel
+    const char* const rod = p.o + (b * p.os[0] + h * p.os[1] + (int64_t)row * p.os[2]) * 2 + hi * 16;
+    if (nt <= 0) {   // rows that see no key (causal, Sq > Sk): no walk, but the dK/dV kernel still reads their delta (P = 0 there: 0 x garbage must stay 0)
+        u32x4 ov[KS], dv[KS];
+        const bool ok = row < p.Sq;
+        const char* rd = dobase + (int64_t)row * bp.dos[2] * 2 + hi * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            ov[s] = dv[s] = u32x4{0u, 0u, 0u, 0u};
+            if (ok) {
+                ov[s] = gload16(rod + s * 32);
+                dv[s] = gload16(rd + s * 32);
+            }
+        }
+        const float dl = row_delta_d64<E>(ov, dv);
+        if (ok && hi == 0) bp.delta[(int64_t)bh * p.Sq + row] = dl;
+    }
     if (nt > 0) {
     // Q^T / dO^T fragments of this wave's rows (B operand: col = row = lane&31, k = 8 contiguous features); Q pre-scaled by scale*log2e
     vec8 qf[KS], dof[KS];
+    u32x4 ofr[KS];   // the row's O chunks (same layout), for delta
     float lse2, dlt;
+    const bool row_ok = row < p.Sq;
     {
-        const bool ok = row < p.Sq;
+        const bool ok = row_ok;
         const char* rq = qbase + (int64_t)row * p.qs[2] * 2 + hi * 16;
         const char* rd = dobase + (int64_t)row * bp.dos[2] * 2 + hi * 16;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             u32x4 a = {0u, 0u, 0u, 0u}, d = {0u, 0u, 0u, 0u};
+            ofr[s] = u32x4{0u, 0u, 0u, 0u};
             if (ok) {
                 a = gload16(rq + s * 32);
                 d = gload16(rd + s * 32);
+                ofr[s] = gload16(rod + s * 32);
             }
             __builtin_memcpy(&qf[s], &a, 16);
             __builtin_memcpy(&dof[s], &d, 16);
         }
         const float l = ok ? p.lse[(int64_t)bh * p.Sq + row] : 0.f;
         lse2 = (l == -INFINITY || l == INFINITY) ? INFINITY : l * kLog2e;   // a row without weights: every P = exp2(-inf) = 0
-        dlt = ok ? bp.delta[(int64_t)bh * p.Sq + row] : 0.f;
     }
     auto tile_dma = [&](int t, int buf) {
         tdK.dma(krw, ldsK_w + buf * TILEB, t * KT, p.ks[2]);
@@ -852,7 +895,16 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
         qf[s] = E::cvt8(f);
     }
     retire_loads(lse2);
-    retire_loads(dlt);
+    {
+        u32x4 dch[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            retire_loads(ofr[s]);
+            __builtin_memcpy(&dch[s], &dof[s], 16);
+        }
+        dlt = row_delta_d64<E>(ofr, dch);
+        if (row_ok && hi == 0) bp.delta[(int64_t)bh * p.Sq + row] = dlt;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         sseed[r] = -lse2;

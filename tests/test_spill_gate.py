@@ -52,7 +52,7 @@ def test_baseline_kernels_do_not_spill(table, pkg):
                     continue
                 rows.append((f"{cfg} {which}", name, table[hit[0]]))
     assert not missing, f"launch-plan names without exactly one code object: {missing}"
-    assert len(rows) >= 4 * len(CONFIGS)   # forward + delta + dQ + dK/dV per config
+    assert len(rows) >= 3 * len(CONFIGS)   # forward + dQ + dK/dV per config (+ delta where the dQ kernel does not compute it itself)
     print()
     for what, n, v in rows:
         print(f"{v.get('vgpr', 0):4d} regs  spill {v.get('spill', 0):3d}  scratch {v.get('scratch', 0):4d} B  {what}: {n[:110]}")
