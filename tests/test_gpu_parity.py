@@ -66,6 +66,46 @@ def test_causal_launches_that_pair_their_blocks(pkg, dev, L, S, dtype):
         _check(v.grad[sl], dv, dtype, f"dv[{b},{h}]")
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_folded_causal_kernel_agrees_with_the_32_row_kernel(pkg, dev, seed):
+    """Causal launches of 2048+ 256-row blocks take the folded two-phase forward kernel (round 5, FOLD in csrc/fasn_fwd_kernel.h: rows folded
+    w / 7 - w, unmasked main walk + per-32-row diagonal walk) and paired pipelined backward kernels; the same inputs one batch element at a
+    time stay below the rule and take the 32-rows-per-wave kernel with single blocks. Random ragged L, S (L != S both ways, bottom-right
+    aligned diagonal, rows without keys), both dtypes: outputs and gradients of the two routes agree to rounding (same arithmetic, other
+    summation order), and a (batch, head) slice agrees with the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    dtype = [torch.float16, torch.bfloat16][seed & 1]
+    B, H, D = 16, 32, 64
+    L = int(rng.integers(1024, 1500))
+    S = int(np.clip(L + rng.integers(-300, 300), 1, None))
+    n = float(rng.choice([0.0, 1.0, 0.5]))
+    if L > S and n == 0.0:
+        n = 1.0   # (rows without a visible key: softmax_0 over an empty set is 0/0 in the oracle; the kernels return zeros)
+    q = _rand((B, H, L, D), dtype, dev, 21 + seed).requires_grad_()
+    k, v = (_rand((B, H, S, D), dtype, dev, s + seed).requires_grad_() for s in (22, 23))
+    do = _rand((B, H, L, D), dtype, dev, 24 + seed, std=1.0)
+    assert B * H * ((L + 255) // 256) >= 2048
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=n, is_causal=True)
+    out.backward(do)
+    big = [t.detach().clone() for t in (out, q.grad, k.grad, v.grad)]
+    q.grad = k.grad = v.grad = None
+    outs = []
+    for b in range(B):
+        ob = pkg.flash_attention_n(q[b:b + 1], k[b:b + 1], v[b:b + 1], softmax_n_param=n, is_causal=True)
+        ob.backward(do[b:b + 1])
+        outs.append(ob.detach())
+    small = [torch.cat(outs), q.grad, k.grad, v.grad]
+    for a, b_, nm in zip(big, small, ("out", "dq", "dk", "dv")):
+        assert torch.isfinite(a).all(), nm
+        scale = max(1.0, b_.float().abs().max().item())
+        err = (a.float() - b_.float()).abs().max().item()
+        assert err <= 4 * REL_TRUE[dtype] * scale, f"{nm}: folded vs 32-row route differ by {err:.3e} (L={L}, S={S}, n={n})"
+    sl = (slice(3, 4), slice(5, 6))
+    o, dq, dk, dv = _oracle_fwd_bwd(q[sl], k[sl], v[sl], do[sl], softmax_n_param=n, is_causal=True)
+    for got, want, nm in ((big[0][sl], o, "out"), (big[1][sl], dq, "dq"), (big[2][sl], dk, "dk"), (big[3][sl], dv, "dv")):
+        _check(got, want, dtype, f"folded {nm} (L={L}, S={S})")
+
+
 # ---------------------------------------------------------------- the backward's scratch
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("case", ["plain", "causal_rows_without_keys", "ragged", "keypad", "gqa", "bias", "dropout", "d32", "d128"])
