@@ -70,6 +70,40 @@ __global__ void __launch_bounds__(256) fasn_bwd_delta_kernel(const BwdParams p) 
     if (gr < rows && sub == 0) p.delta[gr] = acc;
 }
 
+// delta of a lane's row from the row's O and dO chunks, in a kernel where a lane owns a query row (round 5: the dQ kernels of head dims <= 64
+// compute delta = rowsum(O o dO) themselves, in their prologue, and publish it for the dK/dV kernel that follows - fasn_bwd_delta_kernel is
+// not launched there). The lane (row l31, half hi) holds the 16-byte chunks 2s + hi (s = 0 .. KS-1) of its row; the value is BIT-IDENTICAL to
+// the delta kernel's: eight sequential fmas per chunk, then that kernel's xor-1 / xor-2 / ... tree over the 2 KS chunk sums.
+template <typename E, int KS>
+FASN_DEV float row_delta(const u32x4 (&o)[KS], const u32x4 (&d)[KS]) {
+    float pr[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            acc += E::to_f32((uint16_t)(o[s][w] & 0xffff)) * E::to_f32((uint16_t)(d[s][w] & 0xffff));
+            acc += E::to_f32((uint16_t)(o[s][w] >> 16)) * E::to_f32((uint16_t)(d[s][w] >> 16));
+        }
+        pr[s] = acc + __shfl_xor(acc, 32);   // chunk 2s + chunk 2s+1 (the delta kernel's xor-1 level)
+    }
+#pragma unroll
+    for (int o2 = 1; o2 < KS; o2 <<= 1) {   // its xor-2, xor-4, ... levels
+        float nx[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) nx[s] = pr[s] + pr[s ^ o2];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) pr[s] = nx[s];
+    }
+    return pr[0];
+}
+// (D = 128 / 256: the one-wave dQ kernels are at their register limit, and so is the causal D = 32 instantiation with 64 rows per wave - 2 -> 6 spilled
+// registers with the O chunks live in its prologue: delta keeps its launch there)
+#ifndef FASN_DQ_FUSED_DELTA
+#define FASN_DQ_FUSED_DELTA 1   // (A/B: 0 = the one-wave dQ kernels read delta from the delta kernel's launch, as before round 5)
+#endif
+constexpr bool dq_computes_delta(int D, int QB, int MODE) { return FASN_DQ_FUSED_DELTA && (D == 64 || (D == 32 && !(QB == 2 && MODE == MODE_CAUSAL))); }
+
 // shared helpers: stage a [64][D] tile (rows row0..row0+63 of one (b,h) matrix) global -> registers -> swizzled LDS image.
 // Buffer loads through a per-(b,h) descriptor: fixed per-thread byte offset, tile offset in an SGPR, rows past the end of
 // the matrix read back as zeros (no predication, no per-tile vector address arithmetic).
@@ -184,7 +218,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         ntiles = min(ntiles, kmax < 0 ? 0 : (kmax / KT + 1));
     }
 
+    constexpr bool FUSE_DELTA = dq_computes_delta(D, QB, MODE);   // delta = rowsum(O o dO) of the lane's rows computed here and published (row_delta above)
     vec8 qf[QB][KS], dof[QB][KS];
+    u32x4 ofr[FUSE_DELTA ? QB : 1][KS];
     float lse2[QB], dlt[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -192,19 +228,22 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         const bool ok = row < p.Sq;
         const char* rq = qbase + (int64_t)row * p.qs[2] * 2 + hi * 16;
         const char* rd = dobase + (int64_t)row * bp.dos[2] * 2 + hi * 16;
+        const char* ro = p.o + (b * p.os[0] + h * p.os[1] + (int64_t)row * p.os[2]) * 2 + hi * 16;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             u32x4 a = {0u, 0u, 0u, 0u}, d = {0u, 0u, 0u, 0u};
+            if (FUSE_DELTA) ofr[qb][s] = u32x4{0u, 0u, 0u, 0u};
             if (ok) {
                 a = gload16(rq + s * 32);
                 d = gload16(rd + s * 32);
+                if (FUSE_DELTA) ofr[qb][s] = gload16(ro + s * 32);
             }
             __builtin_memcpy(&qf[qb][s], &a, 16);
             __builtin_memcpy(&dof[qb][s], &d, 16);
         }
         float l = ok ? p.lse[(int64_t)bh * p.Sq + row] : 0.f;
         lse2[qb] = (l == -INFINITY) ? INFINITY : l * kLog2e;
-        dlt[qb] = ok ? bp.delta[(int64_t)bh * p.Sq + row] : 0.f;
+        if (!FUSE_DELTA) dlt[qb] = ok ? bp.delta[(int64_t)bh * p.Sq + row] : 0.f;
     }
 
     f32x16 dqacc[QB][DB];
@@ -254,7 +293,19 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
             retire_loads(dof[qb][s]);
         }
         retire_loads(lse2[qb]);
-        retire_loads(dlt[qb]);
+        if constexpr (FUSE_DELTA) {
+            u32x4 dch[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                retire_loads(ofr[qb][s]);
+                __builtin_memcpy(&dch[s], &dof[qb][s], 16);
+            }
+            dlt[qb] = row_delta<E, KS>(ofr[qb], dch);
+            const int row = qw0 + qb * 32 + l31;
+            if (row < p.Sq && hi == 0) bp.delta[(int64_t)bh * p.Sq + row] = dlt[qb];
+        } else {
+            retire_loads(dlt[qb]);
+        }
     }
     // Seeded accumulators (as in the forward): Q is multiplied by c = scale*log2e once, the S accumulator starts at -LSE*log2e
     // and the dP accumulator at -delta, so the element pass is p = exp2(S'), dS = p * dP' - no fma, no subtraction. The seeds are

@@ -34,7 +34,10 @@ template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, i
 int launch_bwd_one(BwdParams p, hipStream_t s) {
     static_assert(!BF32 || (WS == 0 && DROP == 0 && DH == 1), "fp32 bias image: one-wave kernels without dropout");
     const int nbh = p.f.B * p.f.H;
-    if (!(p.skip & 4)) {   // delta (skip bit 2: the pipelined D = 64 dQ kernel computes and publishes it itself, round 5)
+    // delta: its own launch at head dims 128 / 256. At D <= 64 (dq_computes_delta) the dQ kernel - which runs first - computes and publishes it (round 5: row_delta in
+    // fasn_bwd_kernel.h; skip bit 2 = the caller's pipelined dQ kernel does, skip bit 1 without bit 2 = the caller launches its dQ kernel AFTER the
+    // dK/dV kernel of this function, a developer combination that keeps the delta launch)
+    if (!(p.skip & 4) && !(dq_computes_delta(D, QB, MODE) && !(p.skip & 2))) {
         constexpr int RPB = 256 / (D / 8);
         const int64_t rows = (int64_t)nbh * p.f.Sq;
         FASN_LAUNCH((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);

@@ -747,29 +747,6 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dkdv_pipe2_kernel(const BwdPa
 // diagonal and the ragged last key tile zero hidden P in a small wave-uniform branch between B and A.
 constexpr int pipe_dq_smem_bytes() { return 2 * PNB * KT * 64 * 2; }
 
-// delta of a lane's row from the row's O and dO chunks (round 5: the dQ kernel computes delta = rowsum(O o dO) itself, in its prologue, and
-// publishes it for the dK/dV kernel that follows - fasn_bwd_delta_kernel is not launched on this path). The lane (row l31, half hi) holds the
-// 16-byte chunks 2s + hi (s = 0..3) of its row; the value is BIT-IDENTICAL to the delta kernel's: eight sequential fmas per chunk, then
-// the kernel's xor-1 / xor-2 / xor-4 tree over the eight chunk sums ((c0+c1) + (c2+c3)) + ((c4+c5) + (c6+c7)).
-template <typename E>
-FASN_DEV float row_delta_d64(const u32x4 (&o)[4], const u32x4 (&d)[4]) {
-    float c[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        float acc = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            acc += E::to_f32((uint16_t)(o[s][w] & 0xffff)) * E::to_f32((uint16_t)(d[s][w] & 0xffff));
-            acc += E::to_f32((uint16_t)(o[s][w] >> 16)) * E::to_f32((uint16_t)(d[s][w] >> 16));
-        }
-        c[s] = acc;
-    }
-    float pr[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) pr[s] = c[s] + __shfl_xor(c[s], 32);   // chunk 2s + chunk 2s+1
-    return (pr[0] + pr[1]) + (pr[2] + pr[3]);
-}
-
 // DROP = 1: the keep bits are drawn with the exponentials (a lane owns a row: one hash state per key quad, as in the forward) and kept
 // as the SIGN of P until the products; dP starts at 0: dS = |P| o ((kept ? dP / (1-p) : 0) - delta).
 template <typename Tag, int MODE, int DROP = 0>
@@ -828,7 +805,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[d][r] = 0.f;
 
-    // delta = rowsum(O o dO) of the lane's row: computed here (row_delta_d64) and published for the dK/dV kernel
+    // delta = rowsum(O o dO) of the lane's row: computed here (row_delta, fasn_bwd_kernel.h) and published for the dK/dV kernel
     const char* const rod = p.o + (b * p.os[0] + h * p.os[1] + (int64_t)row * p.os[2]) * 2 + hi * 16;
     if (nt <= 0) {   // rows that see no key (causal, Sq > Sk): no walk, but the dK/dV kernel still reads their delta (P = 0 there: 0 x garbage must stay 0)
         u32x4 ov[KS], dv[KS];
@@ -842,7 +819,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
                 dv[s] = gload16(rd + s * 32);
             }
         }
-        const float dl = row_delta_d64<E>(ov, dv);
+        const float dl = row_delta<E, KS>(ov, dv);
         if (ok && hi == 0) bp.delta[(int64_t)bh * p.Sq + row] = dl;
     }
     if (nt > 0) {
@@ -902,7 +879,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
             retire_loads(ofr[s]);
             __builtin_memcpy(&dch[s], &dof[s], 16);
         }
-        dlt = row_delta_d64<E>(ofr, dch);
+        dlt = row_delta<E, KS>(ofr, dch);
         if (row_ok && hi == 0) bp.delta[(int64_t)bh * p.Sq + row] = dlt;
     }
 #pragma unroll
