@@ -53,8 +53,18 @@ def _canon(t: Tensor) -> Tensor:
     return t if _rows_ok(t) else t.contiguous()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the current stream's handle without building a torch.cuda.Stream object (6 us of host time per launch)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream_ptr(device) -> int:
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def _current_device() -> int:
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
 
 
 # ---- dropout stream (reference: torch's philox generator behind core/flash_attn.py:122 and core/functional.py:92) ----
@@ -222,7 +232,7 @@ def _launch_fwd(q, k, v, mask, bias, n, scale, causal, dropout_p, rng):
             if rc:
                 _lib.check(rc, "fasn_fwd")
 
-    if torch.cuda.current_device() == dev.index:   # the usual case: no device-guard object on the plain path
+    if _current_device() == dev.index:   # the usual case: no device-guard object on the plain path
         launch()
     else:
         with torch.cuda.device(dev):
@@ -303,7 +313,7 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
                 _lib.check(rc, "fasn_bwd")
 
         try:
-            if torch.cuda.current_device() == dev.index:   # the usual case: no device-guard object (about 10 us of host time per step)
+            if _current_device() == dev.index:   # the usual case: no device-guard object (about 10 us of host time per step)
                 launch()
             else:
                 with torch.cuda.device(dev):
