@@ -45,6 +45,8 @@ static int dev_variant(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case 91: return launch_fwd_cfg<Tag, 64, 1, 3, 4, 2, 2>(p, l.mode, s);   // the round-4 causal tuning point (32 rows per wave, three workgroups per CU) for any mode
         case 93: return launch_fwd_cfg<Tag, 64, 2, 2, 8, 2, 2>(p, l.mode, s);   // the plain kernel's tuning point with EIGHT waves per workgroup (512 rows share a K/V tile: half the L2 -> LDS traffic, one workgroup per CU)
         case 94: return launch_fwd_cfg<Tag, 64, 1, 2, 8, 2, 2>(p, l.mode, s);   // eight waves x 32 rows, two workgroups per CU
+        case 96: return launch_fwd_ring<Tag, 64, 2, 2, 2, 4, 2>(p, l.mode, s);   // the plain kernel's tuning point with progress-based wave priority (PRIO 4): one-round launches
+        case 97: return launch_fwd_ring<Tag, 64, 1, 3, 2, 4, 2>(p, l.mode, s);   // the 32-row tuning point with it
         case 95: if (l.mode == MODE_CAUSAL) return launch_fwd_one<Tag, 64, 2, MODE_CAUSAL, 2, 8, 2, 2, 0, 1, 1>(p, s); break;   // causal: the folded two-phase walk with eight waves (512-row blocks, rows folded w / 15 - w)
         case 92: if (l.mode == MODE_CAUSAL) return launch_fwd_one<Tag, 64, 2, MODE_CAUSAL, 2, 4, 2, 2, 0, 1, 1>(p, s); break;   // causal: folded two-phase walk whatever the launch size
         case 1: return launch_fwd_mode<Tag, 64, 1, 3>(p, l.mode, s);

@@ -619,6 +619,18 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     const int lane_o = lane, l31_o = l31, hi_o = hi;   // (the names `compute` shadows)
     auto tile_body = [&](const int t, auto LSET, auto SSET, auto DIAG_) {
         constexpr bool DIAG = decltype(DIAG_)::value;
+        if constexpr (PRIO == 4 && NW == 4) {
+            // PRIO 4 (round 5, launches of ONE round): the wave's priority falls with its progress through the key walk, so the two workgroups
+            // that share a CU stay within a quarter of the walk of each other. With the arbiter's oldest-first rule alone the first-dispatched
+            // workgroup of a CU runs ahead and finishes at ~70 % of the span; its partner then runs the last 30 % alone, at half the CU's
+            // throughput (tools/fasn_harness timeline, config 2). Launches of several rounds WANT that stagger (a fresh workgroup's prologue
+            // overlaps the older one's loop) and keep PRIO 0.
+            const int done4 = (t - t_begin) * 4, span = ntiles - t_begin;
+            if (done4 < span) __builtin_amdgcn_s_setprio(3);
+            else if (done4 < 2 * span) __builtin_amdgcn_s_setprio(2);
+            else if (done4 < 3 * span) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // RING 1: the loop is unrolled by two (even tile: LSET = set 0, odd tile: LSET = set 1), so the LDS buffer index is a
         // compile-time constant there and buf*TILEB folds into the ds_read immediate offsets instead of two VALU per read
         // RING 2: the loop is unrolled by three and LSET carries the tile's LDS buffer (t % 3) as a compile-time constant, so the
