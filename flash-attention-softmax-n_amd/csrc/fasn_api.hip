@@ -16,6 +16,8 @@ namespace fasn {
 #ifdef FASN_DEV_VARIANTS
 int g_bwd_variant = 0;
 unsigned long long* g_timeline = nullptr;
+int* g_xq = nullptr;      // developer experiment: dynamic deal of the forward's items across XCDs (fasn_fwd_kernel.h)
+int g_xq_extra = 0;       // surplus workgroups per XCD of such a launch
 int g_pair_mode = -1;
 int g_kprot = 1;
 #endif
@@ -194,6 +196,7 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l, int pass = 0) 
     l.variant = 0;
 #ifdef FASN_DEV_VARIANTS
     p.timeline = g_timeline;
+    p.xq = g_xq;
 #endif
     p.pair = 0;   // set per launch (paired causal blocks, fasn_launch.h)
 #ifdef FASN_DEV_VARIANTS
@@ -350,6 +353,7 @@ void fasn_dev_set_bwd_variant(int v) { fasn::g_bwd_variant = v; }
 void fasn_dev_set_timeline(unsigned long long* buf) { fasn::g_timeline = buf; }
 void fasn_dev_set_pair_mode(int v) { fasn::g_pair_mode = v; }
 void fasn_dev_set_kprot(int v) { fasn::g_kprot = v; }
+void fasn_dev_set_xq(int* counters, int extra) { fasn::g_xq = counters; fasn::g_xq_extra = extra; }
 // developer library only (tools/libfasn_dev.so): forward with an explicit tuning variant, used by tools/fasn_harness
 int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant) {
     FwdParams p;

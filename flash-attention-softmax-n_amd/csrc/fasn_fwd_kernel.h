@@ -84,6 +84,7 @@ struct FwdParams {
     float* part_ml;  // [B*H][nsplit][Sq][2]
 #ifdef FASN_DEV_VARIANTS
     unsigned long long* timeline;   // developer library: per workgroup {t_entry, t_loop, t_epilogue, t_end, hw_id, xcc_id, ntiles, 0} (100 MHz clock)
+    int* xq;                        // developer library, experiment: eight zeroed item counters = a dynamic deal of the (head, query block) items across XCDs
 #endif
 };
 #ifdef FASN_DEV_VARIANTS
@@ -290,6 +291,33 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         block_to_work(wgid, p.B * p.H, (p.nqblk + 1) / 2, bh, qi);
     } else {
         block_to_work(wgid, p.B * p.H, p.nqblk, bh, qi);
+#ifdef FASN_DEV_VARIANTS
+        // Experiment (round 5): the XCDs of a part differ by up to 4 % and each is dealt exactly 1/8 of the workgroups. Here
+        // the ITEMS are dealt dynamically instead: one queue per XCD (its heads' query blocks in the usual order, so an XCD still works on one head
+        // at a time), a workgroup draws from the queue of the XCD it runs on and, when that is empty, from the next non-empty one; the grid carries a
+        // few workgroups more than there are items and the surplus leaves at once. A workgroup still runs ONE item: no loop, no extra registers.
+        if (p.xq != nullptr && ((p.B * p.H) & 7) == 0 && MODE == MODE_PLAIN) {
+            int* const slot = reinterpret_cast<int*>(smem);
+            if (tid == 0) {
+                const int per = (p.B * p.H / 8) * p.nqblk;
+                const int x0 = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7);   // XCC_ID
+                int item = -1, qx = 0;
+                for (int k = 0; k < 8 && item < 0; ++k) {
+                    qx = (x0 + k) & 7;
+                    const int v = atomicAdd(&p.xq[qx], 1);
+                    if (v < per) item = v;
+                }
+                slot[0] = item;
+                slot[1] = qx;
+            }
+            __syncthreads();
+            const int item = slot[0], qx = slot[1];
+            __syncthreads();
+            if (item < 0) return;
+            bh = (item / p.nqblk) * 8 + qx;
+            qi = item % p.nqblk;
+        }
+#endif
     }
     // Paired causal launch: the workgroup dispatcher hands workgroups out IN ORDER and waits for the CU whose turn it is (tools/
     // fasn_harness timeline: with 80..128-tile workgroups next to each other a CU idles until the longest of its round is done), so

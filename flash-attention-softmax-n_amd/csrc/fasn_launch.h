@@ -70,6 +70,8 @@ constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB, int BF32 = 0) 
 constexpr int kPairRounds = 2;   // (measured: C3, 5.3 rounds of single blocks, 0.350 -> 0.335 ms paired; C5, 43 rounds, 2.45 -> 2.39; (4,32,8192,128) 2.19 -> 2.14)
 #ifdef FASN_DEV_VARIANTS
 extern int g_kprot;       // developer library: 0 = no rotated second pass of a length pair (A/B)
+extern int* g_xq;         // developer experiment: item counters of the dynamic deal across XCDs (zeroed here before every launch)
+extern int g_xq_extra;
 extern int g_pair_mode;   // developer library: -1 = shipped rule, 0 = never pair, 1 = always pair (tools/fasn_harness, env FASN_PAIR)
 inline bool pair_wanted(long blocks, long slots) { return g_pair_mode < 0 ? blocks >= kPairRounds * slots : g_pair_mode != 0; }
 #else
@@ -93,6 +95,13 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
 #ifdef FASN_DEV_VARIANTS
     // length-paired batch elements (kpair_plan): developer override through the same switch - 2 = never, 3 = whatever the lengths
     if (mode_has_keypad(MODE) && mode_has_vbias(MODE) && g_pair_mode >= 0) p.pair = g_pair_mode ? 3 : 2;
+#endif
+#ifdef FASN_DEV_VARIANTS
+    if (MODE == MODE_PLAIN && VH == 1 && g_xq != nullptr && ((p.B * p.H) & 7) == 0 && t_launch_log == nullptr) {
+        (void)hipMemsetAsync(g_xq, 0, 8 * sizeof(int), s);
+        FASN_LAUNCH(kern, dim3((unsigned)(blocks * p.B * p.H + 8 * g_xq_extra)), dim3(NW * 64), smem, s, p);
+        return launch_rc();
+    }
 #endif
     FASN_LAUNCH(kern, dim3((unsigned)(blocks * p.B * p.H * VH)), dim3(NW * 64), smem, s, p);
     return launch_rc();

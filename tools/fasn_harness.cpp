@@ -17,6 +17,7 @@
 #include "fasn.h"
 
 extern "C" int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int variant);
+extern "C" void fasn_dev_set_xq(int* counters, int extra);   // experiment: dynamic deal of the forward's items across XCDs, `extra` surplus workgroups per XCD (env FASN_XQ)
 extern "C" void fasn_dev_set_kprot(int v);       // length pairs: rotated key walk of the second element, 1 shipped / 0 off (env FASN_KPROT)
 extern "C" void fasn_dev_set_pair_mode(int v);   // causal block pairing: -1 shipped rule, 0 off, 1 on (env FASN_PAIR)
 extern "C" void fasn_dev_set_timeline(unsigned long long* buf);   // per-workgroup time stamps of the forward kernels (developer library)
@@ -651,6 +652,10 @@ int main(int argc, char** argv) {
     }
     if (const char* pm = getenv("FASN_PAIR")) fasn_dev_set_pair_mode(atoi(pm));
     if (const char* kr = getenv("FASN_KPROT")) fasn_dev_set_kprot(atoi(kr));
+    if (const char* xq = getenv("FASN_XQ")) {
+        int* ctr = nullptr;
+        if (hipMalloc(&ctr, 64) == hipSuccess) fasn_dev_set_xq(ctr, atoi(xq));
+    }
     if (const char* bv = getenv("FASN_BWDV")) fasn_dev_set_bwd_variant(atoi(bv));   // backward kernel variant for `test` (bench takes it as an argument)
     std::string cmd = argv[1];
     if (cmd == "probe") return do_probe();
