@@ -194,9 +194,10 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l, int pass = 0) 
     // push an otherwise representable operand past 65504 there: such calls take the element-load kernels, which scale in fp32.
     if (a->dtype == FASN_DTYPE_F16 && fabsf(p.c) > 8.f) l.mode = MODE_GENERAL_SLOW;
     l.variant = 0;
+    p.xq = nullptr;   // static deal of the items unless fasn_fwd_ws hands over counters (below)
 #ifdef FASN_DEV_VARIANTS
     p.timeline = g_timeline;
-    p.xq = g_xq;
+    if (g_xq != nullptr && pass == 0) p.xq = g_xq;   // (developer harness, env FASN_XQ: forces the dynamic deal of the FORWARD with its own counters and surplus)
 #endif
     p.pair = 0;   // set per launch (paired causal blocks, fasn_launch.h)
 #ifdef FASN_DEV_VARIANTS
@@ -320,13 +321,29 @@ int fasn_fwd_path(const fasn_fwd_args* args) {
     }
 }
 
+// Long plain / causal launches at D = 64 deal their items dynamically across XCDs when the caller hands over 32 bytes of workspace for the eight
+// counters (fasn_fwd_kernel.h: draw_item): from 8 rounds of workgroups (M0's four rounds lose 0.6 % to the memset and the atomics, 16 rounds gain 2 %).
+#ifndef FASN_XQ_RULE
+#define FASN_XQ_RULE 1   // (A/B: 0 = never ask for the counters: static deal everywhere, as before)
+#endif
+static bool xq_wanted(const FwdParams& p, const FwdLaunch& l) {
+    if (!FASN_XQ_RULE) return false;
+    if (l.D != 64 || l.dtype == FASN_DTYPE_F32 || p.drop_thr || ((p.B * p.H) & 7) || p.Sq < 256) return false;
+    const long blocks = (long)((p.Sq + 255) / 256) * p.B * p.H;
+    if (l.mode == MODE_PLAIN) return blocks >= 8 * 512;
+    if (l.mode == MODE_CAUSAL) return blocks >= 2 * 8 * 512;   // (paired blocks: half as many workgroups)
+    return false;
+}
+constexpr size_t kXqBytes = 64;
+
 size_t fasn_fwd_workspace_bytes(const fasn_fwd_args* args) {
     FwdParams p;
     FwdLaunch l;
     if (build_fwd(args, p, l)) return 0;
     int tps;
     const int nsplit = plan_splitk(args, p, l, tps);
-    return nsplit > 1 ? splitk_bytes(args, nsplit) : 0;
+    if (nsplit > 1) return splitk_bytes(args, nsplit);
+    return xq_wanted(p, l) ? kXqBytes : 0;
 }
 
 int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_bytes, fasn_stream_t stream) {
@@ -343,6 +360,10 @@ int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_byt
         p.part_o = static_cast<float*>(workspace);
         p.part_ml = p.part_o + (size_t)args->B * args->H * nsplit * args->Sq * args->D;
         return launch_fwd_splitk(p, l, (hipStream_t)stream);
+    }
+    if (nsplit <= 1 && workspace != nullptr && workspace_bytes >= kXqBytes && xq_wanted(p, l)) {
+        if (reinterpret_cast<uintptr_t>(workspace) % 4) return FASN_EALIGN;
+        p.xq = static_cast<int*>(workspace);
     }
     return dispatch_fwd(p, l, (hipStream_t)stream);
 }

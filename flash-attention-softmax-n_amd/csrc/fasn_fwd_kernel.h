@@ -82,9 +82,9 @@ struct FwdParams {
     int kprot;      // length-paired batch elements: rotate the key walk of the second element (kpair_plan's `lead`); 0 = developer A/B
     float* part_o;   // [B*H][nsplit][Sq][D]
     float* part_ml;  // [B*H][nsplit][Sq][2]
+    int* xq;         // eight zeroed item counters (caller's workspace, fasn_fwd_ws): dynamic deal of the (head, query block) items across XCDs; nullptr = static deal
 #ifdef FASN_DEV_VARIANTS
     unsigned long long* timeline;   // developer library: per workgroup {t_entry, t_loop, t_epilogue, t_end, hw_id, xcc_id, ntiles, 0} (100 MHz clock)
-    int* xq;                        // developer library, experiment: eight zeroed item counters = a dynamic deal of the (head, query block) items across XCDs
 #endif
 };
 #ifdef FASN_DEV_VARIANTS
@@ -189,6 +189,9 @@ FASN_DEV bool kpair_plan(const FwdParams& p, char* scratch, int tid, int slot, i
     return true;
 }
 
+// the instantiations that can deal their items dynamically across XCDs (FwdParams::xq, draw_item below): the plain and causal D = 64 kernels
+constexpr bool fwd_xq_kernel(int D, int MODE, int SPLIT, int VH, int DROP) { return D == 64 && (MODE == MODE_PLAIN || MODE == MODE_CAUSAL) && !SPLIT && VH == 1 && !DROP; }
+constexpr int kXqSurplus = 16;   // surplus workgroups per XCD of such a launch (2 % speed difference of 256 .. 1024 items per XCD is 5 .. 20 items)
 // DROP: attention-weight dropout compiled in (separate instantiations so the no-dropout kernels keep their registers).
 // RING: 1 = two staging register sets, K/V tiles are loaded TWO tiles ahead (the loop body is instantiated twice with the
 // sets swapped). One tile of lead is about 1.2 us at D=64, less than a first-touch HBM miss under load; in-order vmcnt
@@ -244,6 +247,34 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 
     FASN_STAMP(0);
     int bh, qi, split = 0;
+    // Dynamic deal of the work items across XCDs (round 5, long plain / causal launches through fasn_fwd_ws): the XCDs
+    // of a part differ by up to 4 % and the dispatcher deals each exactly 1/8 of the workgroups. With p.xq set the ITEMS are dealt dynamically
+    // instead: one queue per XCD (its heads' query blocks - or block pairs - in the usual order, so an XCD still works on one head at a time), a
+    // workgroup draws from the queue of the XCD it runs on and, when that is empty, from the next non-empty one; the grid carries a few workgroups
+    // more than there are items and the surplus leaves at once. A workgroup still runs ONE item: no loop, no extra registers; results are the
+    // static deal's bit for bit (an item's arithmetic does not depend on who runs it).
+    auto draw_item = [&](const int items_per_head) -> bool {
+        int* const slot = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const int per = (p.B * p.H / 8) * items_per_head;
+            const int x0 = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7);   // XCC_ID
+            int item = -1, qx = 0;
+            for (int k = 0; k < 8 && item < 0; ++k) {
+                qx = (x0 + k) & 7;
+                const int v = atomicAdd(&p.xq[qx], 1);
+                if (v < per) item = v;
+            }
+            slot[0] = item;
+            slot[1] = qx;
+        }
+        __syncthreads();
+        const int item = slot[0], qx = slot[1];
+        __syncthreads();
+        if (item < 0) return false;
+        bh = (item / items_per_head) * 8 + qx;
+        qi = item % items_per_head;
+        return true;
+    };
     const int wgid = VH > 1 ? (int)(blockIdx.x / VH) : (int)blockIdx.x;
     const int dv0 = VH > 1 ? (int)(blockIdx.x % VH) * DB : 0;   // first output column block of this workgroup
     constexpr bool VEC = mode_is_vector(MODE);
@@ -289,35 +320,10 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
         bh = bb * p.H + (rest / p.nqblk) * 8 + xcd;
     } else if (PAIRABLE && p.pair) {
         block_to_work(wgid, p.B * p.H, (p.nqblk + 1) / 2, bh, qi);
+        if (fwd_xq_kernel(D, MODE, SPLIT, VH, DROP) && p.xq != nullptr && !draw_item((p.nqblk + 1) / 2)) return;
     } else {
         block_to_work(wgid, p.B * p.H, p.nqblk, bh, qi);
-#ifdef FASN_DEV_VARIANTS
-        // Experiment (round 5): the XCDs of a part differ by up to 4 % and each is dealt exactly 1/8 of the workgroups. Here
-        // the ITEMS are dealt dynamically instead: one queue per XCD (its heads' query blocks in the usual order, so an XCD still works on one head
-        // at a time), a workgroup draws from the queue of the XCD it runs on and, when that is empty, from the next non-empty one; the grid carries a
-        // few workgroups more than there are items and the surplus leaves at once. A workgroup still runs ONE item: no loop, no extra registers.
-        if (p.xq != nullptr && ((p.B * p.H) & 7) == 0 && MODE == MODE_PLAIN) {
-            int* const slot = reinterpret_cast<int*>(smem);
-            if (tid == 0) {
-                const int per = (p.B * p.H / 8) * p.nqblk;
-                const int x0 = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7);   // XCC_ID
-                int item = -1, qx = 0;
-                for (int k = 0; k < 8 && item < 0; ++k) {
-                    qx = (x0 + k) & 7;
-                    const int v = atomicAdd(&p.xq[qx], 1);
-                    if (v < per) item = v;
-                }
-                slot[0] = item;
-                slot[1] = qx;
-            }
-            __syncthreads();
-            const int item = slot[0], qx = slot[1];
-            __syncthreads();
-            if (item < 0) return;
-            bh = (item / p.nqblk) * 8 + qx;
-            qi = item % p.nqblk;
-        }
-#endif
+        if (fwd_xq_kernel(D, MODE, SPLIT, VH, DROP) && p.xq != nullptr && !draw_item(p.nqblk)) return;
     }
     // Paired causal launch: the workgroup dispatcher hands workgroups out IN ORDER and waits for the CU whose turn it is (tools/
     // fasn_harness timeline: with 80..128-tile workgroups next to each other a CU idles until the longest of its round is done), so

@@ -96,13 +96,18 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
     // length-paired batch elements (kpair_plan): developer override through the same switch - 2 = never, 3 = whatever the lengths
     if (mode_has_keypad(MODE) && mode_has_vbias(MODE) && g_pair_mode >= 0) p.pair = g_pair_mode ? 3 : 2;
 #endif
+    if constexpr (fwd_xq_kernel(D, MODE, 0, VH, DROP)) {
+        if (p.xq != nullptr && ((p.B * p.H) & 7) == 0) {   // dynamic deal of the items across XCDs (fasn_fwd_ws; the counters are the caller's workspace, zeroed here)
+            int surplus = kXqSurplus;
 #ifdef FASN_DEV_VARIANTS
-    if (MODE == MODE_PLAIN && VH == 1 && g_xq != nullptr && ((p.B * p.H) & 7) == 0 && t_launch_log == nullptr) {
-        (void)hipMemsetAsync(g_xq, 0, 8 * sizeof(int), s);
-        FASN_LAUNCH(kern, dim3((unsigned)(blocks * p.B * p.H + 8 * g_xq_extra)), dim3(NW * 64), smem, s, p);
-        return launch_rc();
-    }
+            if (g_xq != nullptr) surplus = g_xq_extra;
 #endif
+            if (t_launch_log == nullptr) (void)hipMemsetAsync(p.xq, 0, 8 * sizeof(int), s);
+            FASN_LAUNCH(kern, dim3((unsigned)(blocks * p.B * p.H + 8 * surplus)), dim3(NW * 64), smem, s, p);
+            return launch_rc();
+        }
+    }
+    p.xq = nullptr;   // (every other instantiation: static deal)
     FASN_LAUNCH(kern, dim3((unsigned)(blocks * p.B * p.H * VH)), dim3(NW * 64), smem, s, p);
     return launch_rc();
 }

@@ -106,6 +106,43 @@ def test_folded_causal_kernel_agrees_with_the_32_row_kernel(pkg, dev, seed):
         _check(got, want, dtype, f"folded {nm} (L={L}, S={S})")
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_dynamic_deal_across_xcds_is_the_static_deal_bit_for_bit(pkg, dev, causal, dtype):
+    """Long plain / causal launches at head dim 64 hand fasn_fwd_ws 64 bytes of workspace and deal their (head, query block) items dynamically
+    across XCDs (round 5, csrc/fasn_fwd_kernel.h: draw_item; eight counters zeroed by the library, surplus workgroups leave at once). Which
+    workgroup runs an item changes nothing about the item: output and LSE must equal the static deal's (fasn_fwd, no workspace) bit for bit,
+    every row written exactly once, twice in a row (the counters are zeroed per launch), also with ragged rows."""
+    from flash_attention_softmax_n_amd import _lib, flash_attn
+    lib = _lib.load()
+    B, H, D = 32, 32, 64
+    L = 1000 if not causal else 2000    # 4 x 1024 (8 x 1024 causal) blocks of 256 rows: the rule's 8 rounds
+    S = L + (24 if causal else 0)
+    q = _rand((B, H, L, D), dtype, dev, 31)
+    k, v = (_rand((B, H, S, D), dtype, dev, s) for s in (32, 33))
+    outs = []
+    for use_ws in (False, True, True):
+        o = torch.full((B, H, L, D), float("nan"), dtype=dtype, device=dev)
+        lse = torch.full((B, H, L), float("nan"), dtype=torch.float32, device=dev)
+        a = _lib.FwdArgs()
+        flash_attn._fill_fwd(a, q, k, v, o, lse, None, None, 1.0, D ** -0.5, causal, 0.0)
+        need = lib.fasn_fwd_workspace_bytes(a)
+        assert need == 64
+        if use_ws:
+            ws = torch.full((need,), 0x5A, dtype=torch.uint8, device=dev)   # (not zero: the library zeroes its counters itself)
+            assert lib.fasn_fwd_ws(a, ws.data_ptr(), need, flash_attn._stream_ptr(dev)) == 0
+        else:
+            assert lib.fasn_fwd(a, flash_attn._stream_ptr(dev)) == 0
+        torch.cuda.synchronize()
+        assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+        outs.append((o, lse))
+    for o, lse in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(lse, outs[0][1])
+    # and the front end takes the workspace route on its own
+    got = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, is_causal=causal)
+    assert torch.equal(got, outs[0][0])
+
+
 # ---------------------------------------------------------------- the backward's scratch
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("case", ["plain", "causal_rows_without_keys", "ragged", "keypad", "gqa", "bias", "dropout", "d32", "d128"])
