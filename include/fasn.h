@@ -158,6 +158,9 @@ int fasn_fwd_path(const fasn_fwd_args* args);
  * (fp32 accumulator + running max / sum per row) are merged by a second kernel. fasn_fwd_workspace_bytes() returns the
  * bytes that plan needs for `args` (0 = the plain path is used; fasn_fwd_ws then equals fasn_fwd). The workspace must be
  * 16-byte aligned device memory; a NULL or too small workspace silently selects the plain path. Same results either way.
+ * Round 5, second use: LONG plain / causal launches at head dim 64 (8+ rounds of workgroups) ask for 64 bytes - eight item counters the
+ * library zeroes itself - and then deal their (head, query block) items dynamically across the XCDs of the part (they differ in speed by up
+ * to 4 %; a static deal ends with the slowest). Bit-identical results; without the workspace the static deal runs.
  */
 size_t fasn_fwd_workspace_bytes(const fasn_fwd_args* args);
 int fasn_fwd_ws(const fasn_fwd_args* args, void* workspace, size_t workspace_bytes, fasn_stream_t stream);
