@@ -2,7 +2,7 @@
 """bench.py — headline benchmark of the hot path (BASELINE.json): attn-ops/s of flash_attention_n at
 (B=8, H=16, S=4096, D=64) bf16, n=1, non-causal, on N replicated GPUs (no sharding, no RCCL on the data path).
 
-  python bench.py --gpus N --steps K --warmup W [--workload m0|c1|c2|c3|c4|c5|d256] [--pass fwd|bwd|fwdbwd]
+  python bench.py --gpus N --steps K --warmup W [--workload m0|c1|c2|c3|c4|c5|d256|t32] [--pass fwd|bwd|fwdbwd]
 
 N > 1: bench.py launches its own N replica processes (one per GPU, gloo control plane over 127.0.0.1) when it is started
 without WORLD_SIZE; started under `python -m torch.distributed.run --nproc-per-node N ...` it joins that world instead.
@@ -37,6 +37,7 @@ WORKLOADS = {
     "c2": (8, 16, 1024, 64, "bf16", 1.0, False),
     "c3": (8, 16, 4096, 64, "f16", 1.0, True),
     "c5": (64, 16, 4096, 64, "bf16", 1.0, True),
+    "t32": (32, 16, 1024, 32, "f16", 1.0, False),    # the shape of the reference's Triton test grid (tests/gpu/core/test_flash_attn_triton.py:21-23): head dim 32, fp16
     "d256": (4, 16, 4096, 256, "bf16", 1.0, False),   # head dim 256 (not a BASELINE config: the reference API's "any E" served natively)
     "c4": (4, 32, 8192, 128, "bf16", 0.5, False),   # + dense ALiBi bias [H,L,S] and key-padding mask [B,1,1,S]
 }

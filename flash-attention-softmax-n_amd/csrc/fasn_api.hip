@@ -68,13 +68,12 @@ int check_view(const fasn_view4& v, bool required, int esize = 2) {
     return FASN_OK;
 }
 
-// fp32 bias next to 16-bit q / k / v on the vector path (round 5): the head dims whose kernels have the fp32 image instantiation,
-// per pass (0 forward, 1 backward). Everything else keeps the element-load kernels for such a bias.
-bool f32_bias_vector(int D, int pass) {
-    (void)pass;   // (head dim 128: on the 4-wave forward and the one-wave backward kernels - the 8-wave forward and the two-wave backward kernels
-                  // have no LDS left for 8 KiB images; head dim 256: element loads)
-    return D == 32 || D == 64 || D == 128;
-}
+// fp32 bias next to 16-bit q / k / v on the vector path (round 5): the head dims whose kernels have the fp32 image instantiation, forward and
+// backward alike (head dims 32 / 64: the usual tuning points; head dim 128: the 8-wave forward with the register-staged two-buffer ring,
+// fasn_fwd_d128.hip, and the ONE-wave backward kernels - the two-wave backward kernels have no LDS left for 8 KiB images; head dim 256: element
+// loads). bias_vec only says that the BIAS is vector-movable: a call whose mode ends up MODE_GENERAL_SLOW for another reason (unaligned dense
+// mask, fp16 scale overflow) still takes the element-load kernels, forward (launch_gen) and backward (launch_bwd_mode).
+bool f32_bias_vector(int D) { return D == 32 || D == 64 || D == 128; }
 
 int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l, int pass = 0) {
     if (a == nullptr) return FASN_EINVAL;
@@ -127,9 +126,9 @@ int build_fwd(const fasn_fwd_args* a, FwdParams& p, FwdLaunch& l, int pass = 0) 
         const int al = 4 * esz;  // 4 keys per load
         bool ok = a->bias.stride[3] == 1 && (reinterpret_cast<uintptr_t>(a->bias.ptr) % al) == 0;
         for (int i = 0; i < 3; ++i) ok = ok && ((a->bias.stride[i] * esz) % al == 0);
-        // scale 0 takes the element-load path; so does an fp32 bias next to 16-bit q / k / v unless this head dim and pass have the fp32 image
+        // scale 0 takes the element-load path; so does an fp32 bias next to 16-bit q / k / v unless this head dim has the fp32 image
         // instantiation (no dropout, no split-K there), and any bias next to fp32 q / k / v (their kernels have the element-load mode only)
-        const bool f32_ok = !p.bias_f32 || (esize == 2 && !(a->dropout_p > 0.f) && f32_bias_vector(a->D, pass));
+        const bool f32_ok = !p.bias_f32 || (esize == 2 && !(a->dropout_p > 0.f) && f32_bias_vector(a->D));
         p.bias_vec = (ok && f32_ok && a->scale > 0.f) ? 1 : 0;
     }
     if (a->mask.ptr) {

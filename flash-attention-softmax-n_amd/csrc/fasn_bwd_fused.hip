@@ -11,7 +11,7 @@ static int launch_bwd_fused(BwdParams p, int mode, hipStream_t s) {
     const int64_t rows = (int64_t)nbh * p.f.Sq;
     constexpr int RPB = 256 / (D / 8);
     FASN_LAUNCH((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
-    if (hipMemsetAsync(p.dqacc, 0, (size_t)rows * D * sizeof(float), s) != hipSuccess) return -6;
+    if (t_launch_log == nullptr && hipMemsetAsync(p.dqacc, 0, (size_t)rows * D * sizeof(float), s) != hipSuccess) return -6;   // (fasn_launch_plan records, it touches no device memory)
     constexpr int smem = fused_smem_bytes();
     p.nblk = (p.f.Sk + FBN - 1) / FBN;
     if (mode == MODE_CAUSAL) {

@@ -102,7 +102,7 @@ FASN_DEV float row_delta(const u32x4 (&o)[KS], const u32x4 (&d)[KS]) {
 #ifndef FASN_DQ_FUSED_DELTA
 #define FASN_DQ_FUSED_DELTA 1   // (A/B: 0 = the one-wave dQ kernels read delta from the delta kernel's launch, as before round 5)
 #endif
-constexpr bool dq_computes_delta(int D, int QB, int MODE) { return FASN_DQ_FUSED_DELTA && (D == 64 || (D == 32 && !(QB == 2 && MODE == MODE_CAUSAL))); }
+constexpr bool dq_computes_delta(int D, int QB, int MODE) { return FASN_DQ_FUSED_DELTA && (D == 64 || D == 32); }
 
 // shared helpers: stage a [64][D] tile (rows row0..row0+63 of one (b,h) matrix) global -> registers -> swizzled LDS image.
 // Buffer loads through a per-(b,h) descriptor: fixed per-thread byte offset, tile offset in an SGPR, rows past the end of
@@ -211,6 +211,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     const char* kbase = p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1]) * 2;
     const char* vbase = p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2;
     const char* dobase = bp.dout + (b * bp.dos[0] + h * bp.dos[1]) * 2;
+    const char* obase = p.o + (b * p.os[0] + h * p.os[1]) * 2;
+    // (causal D = 32 with 64 rows per wave, at its register limit: the vector copy of this base is formed per pass, not in front of the pass
+    // loop and parked in scratch across it)
+    if (D == 32 && QB == 2 && MODE == MODE_CAUSAL) asm volatile("" : "+s"(obase));
 
     int ntiles = (p.Sk + KT - 1) / KT;
     if (causal) {
@@ -228,7 +232,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
         const bool ok = row < p.Sq;
         const char* rq = qbase + (int64_t)row * p.qs[2] * 2 + hi * 16;
         const char* rd = dobase + (int64_t)row * bp.dos[2] * 2 + hi * 16;
-        const char* ro = p.o + (b * p.os[0] + h * p.os[1] + (int64_t)row * p.os[2]) * 2 + hi * 16;
+        const char* ro = obase + (int64_t)row * p.os[2] * 2 + hi * 16;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             u32x4 a = {0u, 0u, 0u, 0u}, d = {0u, 0u, 0u, 0u};
@@ -600,13 +604,18 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 
     if (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the image requested for the tile past the end has landed
     char* dqbase = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1]) * 2;
+    // D = 32 with 64 rows per wave sits at its 256 registers: the output row addresses derive from a FRESH lane id (fasn_common.h) - computed
+    // from the lane id of the kernel entry they are loop invariant, the compiler forms them in front of the tile loop and parks them in
+    // scratch across it (round 5: 7 / 2 spilled registers in the plain / causal instantiation, the reference's own Triton test shape)
+    const int el = (D == 32 && QB == 2) ? fresh_lane_id() : lane;
+    const int e31 = el & 31, ehi = el >> 5;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const int row = qw0 + qb * 32 + l31;
+        const int row = qw0 + qb * 32 + e31;
         if (row < p.Sq) {
             char* rp = dqbase + (int64_t)row * bp.dqs[2] * 2;
 #pragma unroll
-            for (int d = 0; d < DB; ++d) store_block_narrow<E>(rp + d * 64, dqacc[qb][d], bp.scale, hi);   // (8-byte stores: several instantiations at their register limit, fasn_common.h)
+            for (int d = 0; d < DB; ++d) store_block_narrow<E>(rp + d * 64, dqacc[qb][d], bp.scale, ehi);   // (8-byte stores: several instantiations at their register limit, fasn_common.h)
         }
     }
     }   // pass

@@ -29,7 +29,7 @@ extern int g_bwd_variant;
 #endif
 
 // WS = 1: dK / dV by the two-wave kernel (fasn_bwd_dkdv_ws.h); not for dropout or the element-load mode
-// BF32 = 1 (round 5): the one-wave kernels' fp32 bias instantiations (fp32 bias next to 16-bit q / k / v on the vector path; D <= 64)
+// BF32 = 1 (round 5): the one-wave kernels' fp32 bias instantiations (fp32 bias next to 16-bit q / k / v on the vector path; D <= 128)
 template <typename Tag, int D, int QB, int KB, int MODE, int OCC_Q, int OCC_K, int DROP = 0, int WS = 0, int DH = 1, int BF32 = 0>
 int launch_bwd_one(BwdParams p, hipStream_t s) {
     static_assert(!BF32 || (WS == 0 && DROP == 0 && DH == 1), "fp32 bias image: one-wave kernels without dropout");
@@ -129,7 +129,10 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
         }
     }
     if constexpr (D <= 128) {   // fp32 bias next to 16-bit q / k / v on the vector path (fasn_api.hip: f32_bias_vector); D = 128: the ONE-wave kernels (the two-wave ones have no LDS left for 8 KiB images)
-        if (p.f.bias_f32 && p.f.bias_vec) {
+        // Only when the call as a whole is on the vector path: build_fwd leaves bias_vec set for an aligned fp32 bias even when the MODE ends up
+        // MODE_GENERAL_SLOW for another reason (a dense mask whose rows are not 4-byte movable, fp16 with |scale * log2e| > 8) - those calls must take
+        // the element-load kernels below, as the forward's launch_gen does.
+        if (p.f.bias_f32 && p.f.bias_vec && mode != MODE_GENERAL_SLOW) {
             if (mode == MODE_BIAS_KEYPAD) return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), 1, 0, 0, 1, 1>(p, s);
             return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), 1, 0, 0, 1, 1>(p, s);   // bias alone or bias + dense mask
         }

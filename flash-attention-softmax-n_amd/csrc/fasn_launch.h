@@ -102,9 +102,14 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
 #ifdef FASN_DEV_VARIANTS
             if (g_xq != nullptr) surplus = g_xq_extra;
 #endif
-            if (t_launch_log == nullptr) (void)hipMemsetAsync(p.xq, 0, 8 * sizeof(int), s);
-            FASN_LAUNCH(kern, dim3((unsigned)(blocks * p.B * p.H + 8 * surplus)), dim3(NW * 64), smem, s, p);
-            return launch_rc();
+            // counters that could not be zeroed (bad workspace pointer, a capture that refuses the node) would make workgroups skip or repeat
+            // items: such a launch takes the static deal below instead
+            const bool zeroed = t_launch_log != nullptr || hipMemsetAsync(p.xq, 0, 8 * sizeof(int), s) == hipSuccess;
+            if (zeroed) {
+                FASN_LAUNCH(kern, dim3((unsigned)(blocks * p.B * p.H + 8 * surplus)), dim3(NW * 64), smem, s, p);
+                return launch_rc();
+            }
+            (void)hipGetLastError();
         }
     }
     p.xq = nullptr;   // (every other instantiation: static deal)

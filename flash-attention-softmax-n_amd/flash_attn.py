@@ -540,9 +540,17 @@ def slow_attention_n(query: Tensor, key: Tensor, value: Tensor, attn_mask: Optio
                      softmax_dtype=None, train: bool = True) -> Tensor:
     """Signature of functional.py:32-42 on the fused kernel. Accepts (N, ..., L, E) with 3-D or 4-D inputs.
     Float masks are additive (broadcast over leading dims), boolean masks hide keys (the reference's
-    eager version silently ignores boolean masks, functional.py:85-86)."""
+    eager version silently ignores boolean masks, functional.py:85-86).
+    softmax_dtype: the reference casts the softmax_n weights to it (default: query's dtype, functional.py:72-73,91) and multiplies them
+    with `value` next (:93) - so the only values that do not raise there are None and value's own dtype, and for those the weights reach
+    the P.V contraction rounded to value's dtype. That is what the kernel does as well (P is packed to the operand dtype for the MFMA; the
+    scores, the running max and the row sum stay in fp32 registers, where the reference keeps them in query's dtype). Any other
+    softmax_dtype raises the RuntimeError torch's matmul raises in the reference."""
     if is_causal and attn_mask is not None:
         raise AssertionError("attn_mask and is_causal are mutually exclusive")  # functional.py:79
+    if softmax_dtype is not None and softmax_dtype != value.dtype:
+        raise RuntimeError(f"expected m1 and m2 to have the same dtype, but got: {softmax_dtype} != {value.dtype} "
+                           "(softmax_dtype must be None or value's dtype: the weights are multiplied with value next, functional.py:91-93)")
     squeeze = query.dim() == 3
     if squeeze:
         query, key, value = query.unsqueeze(1), key.unsqueeze(1), value.unsqueeze(1)
@@ -557,5 +565,4 @@ def slow_attention_n(query: Tensor, key: Tensor, value: Tensor, attn_mask: Optio
             bias = am
     p = dropout_p if train else 0.0
     out = _attention(query, key, value, softmax_n_param, scale, p, mask, bias, is_causal)
-    # softmax_dtype: the fused kernel keeps the softmax in fp32 registers whatever is asked for
     return out.squeeze(1) if squeeze else out

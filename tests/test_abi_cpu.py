@@ -173,6 +173,20 @@ def test_front_end_refuses_cpu_and_unsupported(pkg):
         pkg.slow_attention_n(q[0], q[0], q[0])
 
 
+def test_slow_attention_n_alias_softmax_dtype_follows_the_reference(pkg):
+    """core/functional.py:72-73,91-93: the softmax_n weights are cast to softmax_dtype (default: query's dtype) and multiplied with value
+    next, so the reference raises torch's dtype-mismatch RuntimeError for any softmax_dtype other than value's dtype (probed against the
+    real reference in the build container: bf16 inputs with softmax_dtype float32 / float16 raise, None / bfloat16 run). The alias raises
+    the same error before it looks at the device; None and value's dtype pass this check (and then hit the CPU-tensor refusal here)."""
+    q = torch.zeros(1, 4, 32, dtype=torch.bfloat16)
+    for sd in (torch.float32, torch.float16):
+        with pytest.raises(RuntimeError, match="same dtype"):
+            pkg.slow_attention_n(q, q, q, softmax_dtype=sd)
+    for sd in (None, torch.bfloat16):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            pkg.slow_attention_n(q, q, q, softmax_dtype=sd)
+
+
 def test_missing_library_fails_loudly(pkg, monkeypatch):
     monkeypatch.setattr(pkg._lib, "_lib", None)
     monkeypatch.setattr(pkg._lib, "LIB_PATH", "/nonexistent/libfasn.so")

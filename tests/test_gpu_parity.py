@@ -253,6 +253,86 @@ def test_flash_attention_analytic(pkg, dev, n, weight, dtype):
     assert torch.allclose(got, N * E * wantc, rtol=rtol, atol=1e-3)
 
 
+# ---------------------------------------------------------------- the reference's Triton test file, same grids (rows a6 / a8 / a9)
+_T_SHAPE = (32, 16, 1024, 32)   # reference tests/gpu/core/test_flash_attn_triton.py:21-23: batch_size (32, 16), L = S = 1024, E = 32, fp16
+_T_SLICES = [(0, 0), (3, 7), (9, 2), (14, 15), (17, 4), (21, 9), (26, 11), (31, 15)]   # (batch, head) slices the CPU oracle is run on
+
+
+def _triton_grid_case(pkg, dev, sm_n, scale, is_causal, atol):
+    """One case of the reference's Triton grid: flash_attention_n_triton(query, key, value, is_causal, scale, softmax_n_param) at the
+    reference's shape and dtype, forward and dq / dk / dv, against slow_attention_n's op sequence in the NATIVE dtype (what the reference test
+    compares with) at the reference's literal atol, rtol 0. The kernel runs the whole (32, 16) batch; the CPU oracle a spread of its
+    (batch, head) slices (the slices of one launch are independent problems), and every element of the full outputs must be finite."""
+    dtype = torch.float16
+    q, k, v = (_rand(_T_SHAPE, dtype, dev, s).requires_grad_() for s in (41, 42, 43))
+    do = _rand(_T_SHAPE, dtype, dev, 44, std=1.0)   # (randn_like(actual): N(0, 1))
+    out = pkg.flash_attention_n_triton(q, k, v, is_causal=is_causal, scale=scale, softmax_n_param=sm_n)
+    assert out.dtype == dtype and out.shape == q.shape
+    out.backward(do)
+    for nm, t in (("out", out), ("dq", q.grad), ("dk", k.grad), ("dv", v.grad)):
+        assert torch.isfinite(t).all(), nm
+    worst = {}
+    for b, h in _T_SLICES:
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        qn, kn, vn = (t.detach()[sl].cpu().requires_grad_() for t in (q, k, v))
+        on = ref_attention_n(qn, kn, vn, softmax_n_param=float(sm_n), scale=scale, is_causal=is_causal)
+        on.backward(do[sl].cpu())
+        for nm, got, want in (("out", out, on), ("dq", q.grad, qn.grad), ("dk", k.grad, kn.grad), ("dv", v.grad, vn.grad)):
+            err = (got.detach()[sl].float().cpu() - want.detach().float()).abs().max().item()
+            worst[nm] = max(worst.get(nm, 0.0), err)
+    for nm, err in worst.items():
+        assert err <= atol, f"{nm}: max-abs {err:.3e} vs native-dtype oracle > the reference's atol {atol} (n={sm_n}, scale={scale}, causal={is_causal})"
+    # and the fp32 "true" answer on one slice, relative gate (the literal atol is loose next to outputs of ~0.02)
+    sl = (slice(3, 4), slice(7, 8))
+    o, dq, dk, dv = _oracle_fwd_bwd(q[sl], k[sl], v[sl], do[sl], softmax_n_param=float(sm_n), scale=scale, is_causal=is_causal)
+    for got, want, nm in ((out[sl], o, "out"), (q.grad[sl], dq, "dq"), (k.grad[sl], dk, "dk"), (v.grad[sl], dv, "dv")):
+        _check(got, want, dtype, f"triton grid {nm} (n={sm_n}, scale={scale}, causal={is_causal})")
+
+
+@pytest.mark.parametrize("scale", [None, 0.5, 0.01, 0.4, 0.3, 0.02])
+@pytest.mark.parametrize("sm_n", [0., 1., 1e-3, 1e-6, 4., 3.])
+def test_triton_signature_reference_grid(pkg, dev, sm_n, scale):
+    """reference tests/gpu/core/test_flash_attn_triton.py:13-48: (32,16,1024,32) fp16, n x scale grid, forward + dq / dk / dv, atol 2e-3."""
+    _triton_grid_case(pkg, dev, sm_n, scale, False, 2e-3)
+
+
+@pytest.mark.parametrize("scale", [None, 0.5, 0.01, 0.4, 0.3, 0.02])
+@pytest.mark.parametrize("sm_n", [0., 1e-6])
+def test_triton_signature_reference_grid_causal(pkg, dev, sm_n, scale):
+    """reference tests/gpu/core/test_flash_attn_triton.py:51-86: the causal grid, atol 2e-2."""
+    _triton_grid_case(pkg, dev, sm_n, scale, True, 2e-2)
+
+
+@pytest.mark.parametrize("scale", [None, 0.01, 0.3, 0.02])
+def test_triton_signature_reference_grid_causal_1em3(pkg, dev, scale):
+    """reference tests/gpu/core/test_flash_attn_triton.py:89-124: causal with n = 1e-3, atol 2e-2."""
+    _triton_grid_case(pkg, dev, 1e-3, scale, True, 2e-2)
+
+
+@pytest.mark.parametrize("weight", [10, 3, 0.5, 0.04, 0.02, 0.01, 0, -0.01, -0.02, -0.04, -0.5, -3, -10])
+@pytest.mark.parametrize("sm_n", [0., 1., 1e-3, 1e-6, 4.])
+def test_triton_signature_analytic(pkg, dev, sm_n, weight):
+    """reference tests/gpu/core/test_flash_attn_triton.py:127-169: Q = K = V = weight, N = 6, L = 1024, S = 1152, E = Ev = 64, scale 0.3, fp16
+    through flash_attention_n_triton: the closed form at atol 1e-3 (the reference's figure) without the causal flag, the causal row sums at
+    rtol 2e-3, and agreement with slow_attention_n's op sequence in fp16 at the same tolerances."""
+    N, L, S, E, scale, dtype = 6, 1024, 1152, 64, 0.3, torch.float16
+    q = weight * torch.ones(N, 1, L, E, device=dev, dtype=dtype)
+    k = weight * torch.ones(N, 1, S, E, device=dev, dtype=dtype)
+    v = weight * torch.ones(N, 1, S, E, device=dev, dtype=dtype)
+    w = float(q[0, 0, 0, 0])   # the weight after rounding to fp16 (the reference's closed form uses the unrounded one and allows 1e-3 for it)
+    a = pkg.flash_attention_n_triton(q, k, v, scale=scale, softmax_n_param=sm_n)
+    assert a.dtype == dtype
+    want = analytic_answer(w, S, E, scale, sm_n)
+    af = a.float().cpu()
+    assert (af - want).abs().max().item() <= 1e-3 + 2.0 ** -10 * abs(want), (sm_n, weight)
+    slow = ref_attention_n(q[:1].cpu(), k[:1].cpu(), v[:1].cpu(), softmax_n_param=sm_n, scale=scale).float()
+    assert (af[:1] - slow).abs().max().item() <= 1e-3 + 2.0 ** -9 * abs(want), (sm_n, weight)
+    b = pkg.flash_attention_n_triton(q, k, v, is_causal=True, scale=scale, softmax_n_param=sm_n).float().cpu()
+    wantc = torch.tensor(analytic_causal_answer(w, L, S, E, scale, sm_n))
+    got = b.sum(dim=0).sum(dim=-1)[0]
+    assert torch.allclose(got, N * E * wantc, rtol=2e-3, atol=1e-6), (sm_n, weight)
+
+
 # ---------------------------------------------------------------- golden fixtures (outputs of the real reference)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("causal", [False, True])
@@ -500,6 +580,63 @@ def test_fp32_bias_next_to_16_bit_inputs(pkg, dev, with_mask, D, dtype):
         _check(got, want, dtype, f"fp32 bias D={D} mask={with_mask} {nm}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("why", ["mask_rows_not_dword_movable", "mask_pointer_misaligned"])
+def test_fp32_bias_with_a_mask_that_forces_element_loads(pkg, dev, why, D, dtype):
+    """An aligned fp32 bias ([1,1,1,S]: vector-movable on its own) next to a dense boolean mask whose rows are NOT 4-byte movable (Sk % 4 != 0,
+    or a mask view that starts at an odd byte): the call as a whole is MODE_GENERAL_SLOW. The forward always took the element-load kernel for it;
+    the backward of round 5 looked at the bias alone and launched the fp32-image vector kernels, which DMA mask rows from misaligned offsets
+    (csrc/fasn_bwd_launch.h). Forward and every gradient against the oracle, and the path query says element loads."""
+    B, H, L = 2, 3, 200
+    S = 331 if why == "mask_rows_not_dword_movable" else 332
+    q, k, v = (_rand(sh, dtype, dev, s).requires_grad_() for sh, s in (((B, H, L, D), 1), ((B, H, S, D), 2), ((B, H, S, D), 3)))
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    bias = (-0.01 * torch.arange(S, dtype=torch.float32, device=dev)).view(1, 1, 1, S) + 0.25
+    gen = torch.Generator().manual_seed(7)
+    if why == "mask_rows_not_dword_movable":
+        mask = (torch.rand(B, H, L, S, generator=gen) < 0.8).to(dev)
+    else:
+        buf = (torch.rand(B * H * L * S + 8, generator=gen) < 0.8).to(dev)
+        mask = buf[1:1 + B * H * L * S].view(B, H, L, S)   # rows of 332 bytes starting at an odd address
+        assert mask.data_ptr() % 4 != 0
+    mask[..., 0] = True
+    from flash_attention_softmax_n_amd.flash_attn import kernel_path
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)   # (the front end says "element loads" once per kind of call)
+        assert kernel_path(q, k, v, attn_mask=mask, attn_bias=bias) == "element-load (slow)"
+        out = pkg.flash_attention_n(q, k, v, softmax_n_param=0.5, attn_mask=mask, attn_bias=bias)
+        out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=0.5, attn_mask=mask, attn_bias=bias)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"fp32 bias + {why} D={D} {nm}")
+
+
+@pytest.mark.parametrize("D", [32, 64, 128])
+def test_fp32_bias_with_an_fp16_scale_that_forbids_prescaled_operands(pkg, dev, D):
+    """fp16 q / k / v with |scale * log2e| > 8 (scale 6: the pre-scaled operand could leave the fp16 range) and an aligned fp32 bias: the forward
+    takes the element-load kernel, which scales in fp32, and so must the backward - round 5's backward launched the fp32-image vector kernels,
+    which pre-scale K in fp16. Inputs small enough that every score is moderate; gradients against the oracle."""
+    dtype = torch.float16
+    B, H, L, S = 2, 2, 160, 264
+    q = (_rand((B, H, L, D), dtype, dev, 1).float() * 0.25).to(dtype).requires_grad_()
+    k = (_rand((B, H, S, D), dtype, dev, 2).float() * 0.25).to(dtype).requires_grad_()
+    v = _rand((B, H, S, D), dtype, dev, 3).requires_grad_()
+    do = _rand((B, H, L, D), dtype, dev, 4, std=1.0)
+    bias = synth.alibi_bias(H, L, S, torch.float32, device=dev)
+    import warnings
+    from flash_attention_softmax_n_amd.flash_attn import kernel_path
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        assert kernel_path(q, k, v, attn_bias=bias, scale=6.0) == "element-load (slow)"
+        out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, scale=6.0, attn_bias=bias)
+        out.backward(do)
+    o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, softmax_n_param=1.0, scale=6.0, attn_bias=bias)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"fp32 bias, fp16 scale 6, D={D} {nm}")
+
+
 @pytest.mark.parametrize("S", [257, 262, 263])
 def test_mask_bias_views_with_odd_key_tails(pkg, dev, S):
     """mask / bias handed over as views into wider buffers: rows stay aligned (vector loads) while the key count leaves a
@@ -645,6 +782,14 @@ def test_real_valued_n_and_signature_aliases(pkg, dev):
         c = pkg.slow_attention_n(q, k, v, softmax_n_param=n)
         assert torch.equal(a, b) and torch.equal(a, c)
         _check(a, ref_attention_n(q.cpu().float(), k.cpu().float(), v.cpu().float(), softmax_n_param=n), dtype, f"n={n}")
+    # softmax_dtype (functional.py:72-73,91): value's dtype is the only one the reference's matmul accepts; the weights reach P.V rounded to it,
+    # as in the kernel - same result as the default, within the reference's bf16 atol of the native-dtype op sequence
+    e = pkg.slow_attention_n(q, k, v, softmax_n_param=1.0, softmax_dtype=dtype)
+    assert torch.equal(e, pkg.slow_attention_n(q, k, v, softmax_n_param=1.0))
+    native = ref_attention_n(q.cpu(), k.cpu(), v.cpu(), softmax_n_param=1.0).float()
+    assert (e.float().cpu() - native).abs().max().item() <= REF_ATOL[dtype]
+    with pytest.raises(RuntimeError, match="same dtype"):
+        pkg.slow_attention_n(q, k, v, softmax_n_param=1.0, softmax_dtype=torch.float32)
     fm = torch.randn(128, 128).to(dev)
     d = pkg.slow_attention_n(q[0], k[0], v[0], attn_mask=fm, softmax_n_param=1.0)   # 3-D inputs + (L,S) float mask
     _check(d, ref_attention_n(q[0].cpu().float(), k[0].cpu().float(), v[0].cpu().float(), softmax_n_param=1.0, attn_bias=fm.cpu()),
