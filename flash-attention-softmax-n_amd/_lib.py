@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasn.so")
 
-FASN_ABI_VERSION = 5
+FASN_ABI_VERSION = 6
 FASN_BWD_ONE_PASS = 1
 FASN_DTYPE_F16, FASN_DTYPE_BF16, FASN_DTYPE_F32 = 0, 1, 2
 FASN_BIAS_NONE, FASN_BIAS_SAME, FASN_BIAS_F32 = 0, 1, 2
@@ -119,8 +119,25 @@ def launch_plan(args, which):
         check(rc, "fasn_launch_plan")
     out = []
     for line in buf.value.decode().splitlines():
-        name, g, b, l = line.rsplit(" ", 3)
+        name, g, b, l, _cfg = line.rsplit(" ", 4)
         out.append((name, int(g.split("=")[1]), int(b.split("=")[1]), int(l.split("=")[1])))
+    return out
+
+
+def launch_plan_described(args, which):
+    """The same plan as (kernel family<named template arguments>, grid, block, lds bytes): the `cfg` field of the plan lines (ABI 6) names the
+    positional template arguments - fasn_fwd_kernel<bf16,D=64,QB=2,plain,OCC=2,NW=4,RING=2,SEED=2> instead of
+    fasn_fwd_kernel<fasn::bf16_tag, 64, 2, 0, 2, 4, 0, 0, 2, 0, 2, 1, 0, 0>. What bench.py prints as roofline.kernels."""
+    buf = ctypes.create_string_buffer(8192)
+    rc = load().fasn_launch_plan(args, which, buf, len(buf))
+    if rc < 0:
+        check(rc, "fasn_launch_plan")
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, g, b, l, cfg = line.rsplit(" ", 4)
+        cfg = cfg.split("=", 1)[1]
+        shown = name if cfg == "-" else f"{name.split('<', 1)[0]}<{cfg}>"
+        out.append((shown, int(g.split("=")[1]), int(b.split("=")[1]), int(l.split("=")[1])))
     return out
 
 

@@ -24,6 +24,79 @@ int g_kprot = 1;
 thread_local LaunchLog* t_launch_log = nullptr;
 // one line per launch: the kernel with its template arguments (demangled from the type name kernel_pretty_name<&kernel<...>> hands over:
 // "fasn::KernelTag<&(void fasn::kernel<arguments>(fasn::Params))>"), grid, block, LDS
+// "bf16,D=64,QB=2,plain,OCC=2,NW=4,RING=2,SEED=2" for "fasn_fwd_kernel<fasn::bf16_tag, 64, 2, 0, 2, 4, 0, 0, 2, 0, 2, 1, 0, 0>": the template
+// arguments of the kernel families by NAME (flags that are off and unit factors are left out), so that a launch plan, a profile line or a
+// spill table can be read without the kernel headers open. Unknown kernels: empty string.
+static size_t describe_kernel(const char* name, size_t n, char* out, size_t cap) {
+    struct Family { const char* base; const char* params; };   // params: names in template order; '!' prefix = omit when 0, '1' prefix = omit when 1, 'M' = mode, 'T' = element tag
+    static const Family families[] = {
+        {"fasn_fwd_kernel", "T D QB M OCC NW !PRIO !DROP RING !SPLIT SEED 1VH !FOLD !BF32"},
+        {"fasn_bwd_dq_kernel", "T D QB M OCC !DROP DQ_SEED !BF32"},
+        {"fasn_bwd_dkdv_kernel", "T D KB M OCC !DROP !GQA 1DH !BF32"},
+        {"fasn_bwd_dq_ws_kernel", "T D M !DROP"},
+        {"fasn_bwd_dkdv_ws_kernel", "T D M !GQA !DROP"},
+        {"fasn_bwd_dq_pipe_kernel", "T M !DROP"},
+        {"fasn_bwd_dkdv_pipe_kernel", "T M !DROP"},
+        {"fasn_bwd_dq_ws256_kernel", "T M"},
+        {"fasn_bwd_dkdv_ws256_kernel", "T M !GQA"},
+        {"fasn_fwd_ws256_kernel", "T M"},
+        {"fasn_bwd_delta_kernel", "T D"},
+        {"fasn_fwd_combine_kernel", "T D"},
+        {"fasn_bwd_dbias_ws_kernel", "T D"},
+        {"fasn_bwd_dbias_kernel", "T D FAST"},
+        {"fasn_f32_fwd_kernel", "D M"},
+        {"fasn_f32_dq_kernel", "D M"},
+        {"fasn_f32_dkdv_kernel", "D M"},
+        {"fasn_f32_delta_kernel", "D"},
+    };
+    static const char* const modes[] = {"plain", "causal", "bias+mask", "element-load", "bias", "mask", "keypad", "bias+keypad"};
+    if (cap == 0) return 0;
+    out[0] = 0;
+    const char* lt = (const char*)memchr(name, '<', n);
+    if (lt == nullptr) return 0;
+    const Family* fam = nullptr;
+    for (const Family& f : families)
+        if (strlen(f.base) == (size_t)(lt - name) && strncmp(f.base, name, (size_t)(lt - name)) == 0) fam = &f;
+    if (fam == nullptr) return 0;
+    size_t len = 0;
+    auto put = [&](const char* t, size_t tn) {
+        if (len + tn + 1 < cap) {
+            memcpy(out + len, t, tn);
+            len += tn;
+            out[len] = 0;
+        }
+    };
+    const char* a = lt + 1;
+    const char* pn = fam->params;
+    const char* const end = name + n;
+    while (a < end && *pn) {
+        const char* ae = a;   // one template argument: up to the next ',' or the closing '>' (the arguments here are flat: types and integers)
+        while (ae < end && *ae != ',' && *ae != '>') ++ae;
+        const char* pe = pn;
+        while (*pe && *pe != ' ') ++pe;
+        while (a < ae && *a == ' ') ++a;
+        char val[48];
+        const size_t vn = (size_t)(ae - a) < sizeof val - 1 ? (size_t)(ae - a) : sizeof val - 1;
+        memcpy(val, a, vn);
+        val[vn] = 0;
+        const long num = strtol(val, nullptr, 10);
+        char item[96];
+        int in = 0;
+        if (*pn == 'T' && pe - pn == 1) in = snprintf(item, sizeof item, "%s", strstr(val, "bf16") ? "bf16" : "f16");
+        else if (*pn == 'M' && pe - pn == 1) in = snprintf(item, sizeof item, "%s", (num >= 0 && num < 8) ? modes[num] : val);
+        else if (*pn == '!') { if (strcmp(val, "0") != 0 && strcmp(val, "false") != 0) in = snprintf(item, sizeof item, "%.*s=%s", (int)(pe - pn - 1), pn + 1, val); }
+        else if (*pn == '1') { if (num != 1) in = snprintf(item, sizeof item, "%.*s=%s", (int)(pe - pn - 1), pn + 1, val); }
+        else in = snprintf(item, sizeof item, "%.*s=%s", (int)(pe - pn), pn, val);
+        if (in > 0) {
+            if (len) put(",", 1);
+            put(item, (size_t)in);
+        }
+        a = ae < end ? ae + 1 : end;
+        pn = *pe ? pe + 1 : pe;
+    }
+    return len;
+}
+
 void log_launch(const char* tag_name, unsigned grid, unsigned block, int smem) {
     LaunchLog* const g = t_launch_log;
     if (g == nullptr) return;
@@ -38,8 +111,10 @@ void log_launch(const char* tag_name, unsigned grid, unsigned block, int smem) {
         else if (b[n] == '>') --depth;
         else if (b[n] == '(' && depth == 0) break;
     }
-    char tail[96];
-    const int tn = snprintf(tail, sizeof tail, " grid=%u block=%u lds=%d\n", grid, block, smem);
+    char cfg[192];
+    describe_kernel(b, n, cfg, sizeof cfg);
+    char tail[320];
+    const int tn = snprintf(tail, sizeof tail, " grid=%u block=%u lds=%d cfg=%s\n", grid, block, smem, cfg[0] ? cfg : "-");
     if (g->len + n + (size_t)tn + 1 > g->cap) {   // does not fit: remember that by moving len past cap (the caller reports FASN_EINVAL)
         g->len = g->cap + 1;
     } else {
@@ -385,7 +460,7 @@ int fasn_fwd_variant(const fasn_fwd_args* args, fasn_stream_t stream, int varian
 }
 #endif
 
-// One-pass backward (fasn_bwd_fused.h): a measured loser on MI355X, kept in the DEVELOPER library only
+// One-pass backward (tools/dev/fasn_bwd_fused.h): a measured loser on MI355X, kept in the DEVELOPER library only
 // (tools/libfasn_dev.so, FASN_DEV_VARIANTS) for A/B work; libfasn.so ignores FASN_BWD_ONE_PASS and never asks for a workspace.
 static bool bwd_fused_applies(const fasn_bwd_args* a, const FwdParams& p, const FwdLaunch& l) {
 #ifndef FASN_DEV_VARIANTS

@@ -61,7 +61,9 @@ static int go(const BwdParams& p, int mode, hipStream_t s) {
         if (p.f.kvg == 1 && mode == MODE_KEYPAD && p.f.ms[3] == 1 && (p.f.Sk + 63) / 64 <= kDq256KpTiles) return launch_ws256<Tag, MODE_KEYPAD>(p, s);
     }
     switch (mode) {
+#ifdef FASN_DEV_VARIANTS   // (plain and causal calls always take the two-wave kernels above: the one-wave causal instantiation is reachable from the A/B switch only)
         case MODE_CAUSAL: return launch_bwd_one<Tag, 256, 1, 1, MODE_CAUSAL, 1, 1, 0, 0, 2>(p, s);
+#endif
         case MODE_PLAIN:   // the key-padding instantiation without a mask (every key visible): the plain one spills at this head dim
         case MODE_KEYPAD: return launch_bwd_one<Tag, 256, 1, 1, MODE_KEYPAD, 1, 1, 0, 0, 2>(p, s);
         // dense masks / bias: the element-load kernels (the dK/dV kernel's additive tile next to four 32 KiB Q / dO buffers would

@@ -148,7 +148,8 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     const int key = kw0 + l31;
     const int coff = p.Sk - p.Sq;
     const int bh_drop = b * p.H + h;        // (dropout instantiations: one query head per K/V head)
-    const DropLane dlane = drop_lane(key & 3);
+    const DropLane dlane = drop_lane(key);
+    const DropThr dthr = drop_thr(DROP ? p.drop_thr : 1u);
 
     const char* kbase = p.k + (b * p.ks[0] + hk * p.ks[1]) * 2;
     const char* vbase = p.v + (b * p.vs[0] + hk * p.vs[1]) * 2;
@@ -360,10 +361,9 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
             }
         };
         auto soft = [&](int qb, const f32x16& sacc, vec8 (&pfr)[2], auto MASKED) {   // P = exp2(S'), packed, and published for wave B
-            vec8 pub[2];   // (DROP: what wave B gets - sign set on dropped weights; pfr keeps the kept weights for dV)
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
-                f32x8 x, xs;
+                f32x8 x;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int r = 8 * t2 + e;
@@ -374,31 +374,21 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
                         pv = show ? pv : 0.f;
                     }
                     x[e] = pv;
-                    xs[e] = pv;
                     if (DROP) {
                         // the state of (row, key quad): computed by the lane of the quad whose key & 3 equals the row's place in its
                         // 4-row register group, fetched from it with a quad_perm broadcast (r & 3 is a compile-time constant here)
                         const int g = r >> 2;
-                        const uint32_t own = drop_mix(drop_row_base(dsd.lo, (uint32_t)bh_drop, (uint32_t)(r0 + qb * 32 + 8 * g + 4 * hi + (lane & 3))), dsd.hi, (uint32_t)(key >> 2));   // (one per g: CSE)
-                        uint32_t hy;
-                        switch (r & 3) {   // quad_perm broadcast of lane (quad base + (r & 3))
-                            case 0: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0x00, 0xf, 0xf, false); break;
-                            case 1: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0x55, 0xf, 0xf, false); break;
-                            case 2: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xAA, 0xf, 0xf, false); break;
-                            default: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xFF, 0xf, 0xf, false); break;
-                        }
-                        const bool keep = drop_keep(drop_word(hy, dlane), p.drop_thr << 16);
-                        x[e] = keep ? pv : 0.f;
-                        xs[e] = keep ? pv : -pv;
+                        const uint32_t own = drop_mix(drop_row_base(dsd.lo, (uint32_t)bh_drop, (uint32_t)(r0 + qb * 32 + 8 * g + 4 * hi + (lane & 3))), dsd.hi, (uint32_t)(key >> 4));   // (one per g: CSE)
+                        const bool keep = (int32_t)drop_word(quad_bcast(own, r & 3), dlane) >= dthr.hi32;
+                        x[e] = keep ? pv : -pv;   // sign set = dropped (P is never negative): what wave B reads
                     }
                 }
                 pfr[t2] = E::cvt8(x);
-                if (DROP) pub[t2] = E::cvt8(xs);
             }
             char* ps = pslot(pb, qb);   // lane to same lane, 2 x 16 bytes
             u32x4 w0, w1;
-            __builtin_memcpy(&w0, DROP ? &pub[0] : &pfr[0], 16);
-            __builtin_memcpy(&w1, DROP ? &pub[1] : &pfr[1], 16);
+            __builtin_memcpy(&w0, &pfr[0], 16);
+            __builtin_memcpy(&w1, &pfr[1], 16);
             if (KPD) {   // key padding: the lane's key is hidden for every row - clear its packed weights (also what dV multiplies)
                 const uint32_t kpm = kp_keep ? 0xffffffffu : 0u;
 #pragma unroll
@@ -406,21 +396,29 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
                     w0[e] &= kpm;
                     w1[e] &= kpm;
                 }
-                if (DROP) {   // (the kept weights of dV are a different pair of registers)
-                    u32x4 v0, v1;
-                    __builtin_memcpy(&v0, &pfr[0], 16);
-                    __builtin_memcpy(&v1, &pfr[1], 16);
+            }
+            if (DROP) {   // the kept weights for this wave's own dV GEMM: the published pairs with the flagged halves cleared (two packed instructions per pair)
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                u32x4 v0 = w0, v1 = w1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v0[e] &= kpm;
-                        v1[e] &= kpm;
-                    }
-                    __builtin_memcpy(&pfr[0], &v0, 16);
-                    __builtin_memcpy(&pfr[1], &v1, 16);
-                } else {
-                    __builtin_memcpy(&pfr[0], &w0, 16);
-                    __builtin_memcpy(&pfr[1], &w1, 16);
+                for (int i = 0; i < 4; ++i) {
+                    s16x2 h0, h1;
+                    const uint32_t a0 = v0[i], a1 = v1[i];
+                    __builtin_memcpy(&h0, &a0, 4);
+                    __builtin_memcpy(&h1, &a1, 4);
+                    h0 = h0 >> (short)15;   // 0xffff in the dropped halves
+                    h1 = h1 >> (short)15;
+                    uint32_t m0, m1;
+                    __builtin_memcpy(&m0, &h0, 4);
+                    __builtin_memcpy(&m1, &h1, 4);
+                    v0[i] &= ~m0;
+                    v1[i] &= ~m1;
                 }
+                __builtin_memcpy(&pfr[0], &v0, 16);
+                __builtin_memcpy(&pfr[1], &v1, 16);
+            } else if (KPD) {
+                __builtin_memcpy(&pfr[0], &w0, 16);
+                __builtin_memcpy(&pfr[1], &w1, 16);
             }
             *LDS_PTR(u32x4, ps) = w0;
             *LDS_PTR(u32x4, ps + 1024) = w1;
@@ -443,7 +441,9 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
         vec8 pfr[2];
         auto block = [&](int qb) {
             s_gemm(qb, sacc);
-            if (need_mask) soft(qb, sacc, pfr, std::true_type{});
+            // (dropout instantiations: ONE copy of the element pass - the masked one; with two the compiler keeps both sets of hoisted
+            // addresses and hash constants live and spills 20 - 60 registers into the tile loop)
+            if (DROP || need_mask) soft(qb, sacc, pfr, std::true_type{});
             else soft(qb, sacc, pfr, std::false_type{});
             dv_gemm(qb, pfr);
         };

@@ -234,6 +234,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
     const int wave_last_vis = qw0 + 31 + coff;
     const int vis = causal ? (row + coff) : 0x7fffffff;
     const uint32_t drop_rb = DROP ? drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row) : 0u;
+    const DropThr dthr = drop_thr(DROP ? p.drop_thr : 1u);
+    const uint32_t drop_rh = drop_rh_of(hi);
     // wave-uniform classification of (this wave's 32 rows) x (key tile t): identical for the A and the B wave of a row block
     auto classify = [&](int t, bool& skip, bool& need_mask, uint64_t& kp_bits) {   // t: the tile itself (phys(step))
         const int k0 = t * KT;
@@ -313,6 +315,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
             } else {
                 sacc = s_gemm(seed);
             }
+            const DropBlock<KPERM> db(drop_rb, dsd.hi, (uint32_t)((t * KT + kb * 32) >> 4), hi, drop_rh);   // DROP: the states of the lane's 16 weights of this block (fasn_common.h)
             auto elems = [&](auto MASKED) {
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) {
@@ -325,10 +328,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
                             const int key = key_of(t, kb, r);
                             pv = ((key < p.Sk) && (key <= vis)) ? pv : 0.f;
                         }
-                        if (DROP) {   // registers 4g .. 4g+3 are one key quad: one state per quad, the word of key & 3 = r & 3 (CSE'd over the quad)
-                            const uint32_t hy = drop_mix(drop_rb, dsd.hi, (uint32_t)(key_of(t, kb, r & ~3) >> 2));
-                            pv = drop_keep(drop_word(hy, r & 3), p.drop_thr << 16) ? pv : -pv;
-                        }
+                        if (DROP) pv = db.keep(r, dthr) ? pv : -pv;   // (sign set = dropped: what wave B reads)
                         x[e] = pv;
                     }
                     pf[kb][t2] = E::cvt8(x);

@@ -36,7 +36,7 @@ struct BwdParams {
     char* dbias;       // optional: dS written densely [B,H,Sq,Sk] (element type of q), key stride 1; nullptr = not wanted
     int64_t dbs[3];
     int dbias_vec;     // rows 16-byte aligned: 8 keys per store on the vector path
-    float* dqacc;      // fused backward (fasn_bwd_fused.h): fp32 dQ accumulator [B,H,Sq,D] in the caller's workspace; nullptr = split kernels
+    float* dqacc;      // fused backward (developer library, tools/dev/fasn_bwd_fused.h): fp32 dQ accumulator [B,H,Sq,D] in the caller's workspace; nullptr = split kernels
     int skip;          // host side only (launch_bwd_one): bit 0 = dK/dV, bit 1 = dQ are launched by the caller (fasn_bwd_pipe.h kernels)
 };
 
@@ -192,6 +192,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     const int l31 = lane & 31;
     const int hi = lane >> 5;
     const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
+    const DropThr dthr = drop_thr(DROP ? p.drop_thr : 1u);
+    const uint32_t drop_rh = drop_rh_of(hi);
 
     int bh, qi;
     const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
@@ -388,6 +390,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
 
     const int wave_first_vis = qw0 + coff;
     const int wave_last_vis = qw0 + QB * 32 - 1 + coff;
+    uint32_t drop_rb[QB];   // DROP: the row part of the hash input, once per row block (two 32-bit multiplies)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) drop_rb[qb] = DROP ? drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)(qw0 + qb * 32 + l31)) : 0u;
 
     // MODE_KEYPAD (mask = one byte per key of the (b,h), no bias), as in the forward: each lane fetches the byte of key
     // k0 + lane one tile ahead, a ballot makes the tile's visibility word; all-visible tiles are plain, all-hidden ones skipped
@@ -503,6 +508,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                 for (int qb = 0; qb < QB; ++qb) {
                     const int row = qw0 + qb * 32 + l31;
                     const int vis = causal ? (row + coff) : 0x7fffffff;
+                    // DROP: the (row, key group) states of the lane's 16 weights of this block (fasn_common.h: DropBlock)
+                    const DropBlock<VEC> db(drop_rb[qb], dsd.hi, (uint32_t)((k0 + kb * 32) >> 4), hi, drop_rh);
                     auto elems = [&](auto MASKED) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -530,15 +537,14 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                                        : SEED_S ? fast_exp2(sacc[qb][r]) : fast_exp2(__builtin_fmaf(sacc[qb][r], p.c, -lse2[qb]));
                             if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                             float dp = pacc[qb][r];
-                            if (DROP) {   // same keep bits as the forward (same lane layout: lane = row, 4 keys per hash)
-                                const uint32_t rb = drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row);
-                                const uint32_t hy = drop_mix(rb, dsd.hi, (uint32_t)((k0 + kb * 32 + (VEC ? 16 * hi + 4 * (r >> 2) : 8 * (r >> 2) + 4 * hi)) >> 2));   // (shared by the 4 keys of the quad: CSE)
-                                dp = drop_keep(drop_word(hy, r & 3), p.drop_thr << 16) ? dp * p.drop_scale : 0.f;
+                            if (DROP) {   // same keep bits as the forward (same lane layout: lane = row)
+                                dp = db.keep(r, dthr) ? dp * p.drop_scale : 0.f;
                             }
                             sacc[qb][r] = SEED_P ? pv * dp : pv * (dp - dlt[qb]);
                         }
                     };
-                    if (need_mask) elems(std::true_type{});
+                    // (dropout instantiations: ONE copy of the element pass - the masked one; two copies keep two sets of hash temporaries live)
+                    if (DROP || need_mask) elems(std::true_type{});
                     else elems(std::false_type{});
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {
@@ -656,6 +662,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     const int l31 = lane & 31;
     const int hi = lane >> 5;
     const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
+    const DropThr dthr = drop_thr(DROP ? p.drop_thr : 1u);
+    const DropLane dlane = drop_lane((int)(threadIdx.x & 31));   // (a wave's key blocks start at multiples of 32: the key's place in its 16-key group is lane & 15)
 
     const int kvg = GQA ? p.kvg : 1;
     const int Hkv = p.H / kvg;
@@ -1009,18 +1017,21 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                         if (decltype(MASKED)::value) pv = show ? pv : 0.f;
                         float dp = pacc[kb][r];
                         float pd = pv;
-                        if (DROP) {   // lane = key here: one state per element, the word of key & 3 (rotation / multiplier picked per lane)
-                            const int row = r0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            const uint32_t rb = drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row);
-                            const bool keep = drop_keep(drop_word(drop_mix(rb, dsd.hi, (uint32_t)(key >> 2)), drop_lane(key & 3)), p.drop_thr << 16);
-                            dp = keep ? dp * p.drop_scale : 0.f;
-                            pd = keep ? pv * p.drop_scale : 0.f;
+                        if (DROP) {   // lane = key here: the state of the register's row comes from the lane of the key quad that computed it
+                            // (the state of row 8 g + 4 hi + (lane & 3) of the block and this lane's key group: one per register group g - CSE - fetched from
+                            // the lane of the key quad that computed it, fasn_common.h: quad_bcast)
+                            const uint32_t own = drop_mix(drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)(r0 + qb * 32 + 8 * (r >> 2) + 4 * hi + (lane & 3))), dsd.hi, (uint32_t)(key >> 4));
+                            const bool keep = (int32_t)drop_word(quad_bcast(own, r & 3), dlane) >= dthr.hi32;
+                            const float ks = keep ? p.drop_scale : 0.f;   // (one select: the factor, 1 / (1 - p) or 0)
+                            dp *= ks;
+                            pd = pv * ks;
                         }
                         sacc[kb][r] = pd;                     // dropped weights feed dV
                         pacc[kb][r] = SEED_P ? pv * dp : pv * (dp - xr[r]);      // dS uses the undropped P
                     }
                     };
-                    if (need_mask) elems(std::true_type{});
+                    // (dropout instantiations: ONE copy of the element pass - the masked one)
+                    if (DROP || need_mask) elems(std::true_type{});
                     else elems(std::false_type{});
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {

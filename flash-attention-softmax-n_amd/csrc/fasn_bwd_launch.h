@@ -13,7 +13,7 @@ int launch_bwd_d32(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d128(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_d256(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
-int launch_bwd_fused_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);   // one-pass backward (fasn_bwd_fused.h), p.dqacc set
+int launch_bwd_fused_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);   // one-pass backward (developer library only: tools/dev/fasn_bwd_fused.h), p.dqacc set
 int launch_bwd_dkdv_pipe_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);
 int launch_bwd_dkdv_pipe2_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);  // the same with one wave per SIMD and 64 keys per wave (developer A/B)
 int launch_bwd_dq_pipe_d64(const BwdParams& p, const FwdLaunch& l, hipStream_t s);     // software-pipelined dQ   // software-pipelined dK/dV (fasn_bwd_pipe.h): plain / causal
@@ -43,9 +43,19 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         FASN_LAUNCH((fasn_bwd_delta_kernel<Tag, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
     }
     bool dq_done = (p.skip & 2) != 0;
-    if constexpr (WS != 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
-        const int ntiles = (p.f.Sk + KT - 1) / KT;
-        if (!dq_done && !(FASN_BWD_VARIANT & 2) && (!mode_has_keypad(MODE) || ntiles <= kDqWsMaxTiles) && (!DROP || p.f.kvg == 1)) {   // dQ: two cooperating waves per row block
+    // the two-wave kernels (WS) serve every call of their modes except dropout with grouped K/V; the one-wave kernels of those modes are
+    // instantiated only where they can be reached (dropout instantiations, developer A/B builds) - the plain / causal / key-padding / bias
+    // one-wave dQ kernels at D = 128 spilled 11 - 15 registers and were dead code in libfasn.so
+    constexpr bool WS_MODE = WS != 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE);
+#ifdef FASN_DEV_VARIANTS
+    constexpr bool ONE_WAVE = true;
+#else
+    constexpr bool ONE_WAVE = !WS_MODE || DROP != 0;
+#endif
+    // a key-padding mode always fits the dQ kernel's visibility table: build_fwd hands out MODE_KEYPAD / MODE_BIAS_KEYPAD only up to the FORWARD's table
+    static_assert(kFwdKpMaxTiles <= kDqWsMaxTiles, "key-padding modes: the forward's visibility table bounds the key range, the dQ kernel's must hold it");
+    if constexpr (WS_MODE) {
+        if (!dq_done && !(FASN_BWD_VARIANT & 2) && (!DROP || p.f.kvg == 1)) {   // dQ: two cooperating waves per row block
             constexpr int smem = 5 * KT * D * 2 + 2 * 16384 + (mode_has_vbias(MODE) ? 32768 : 0) + (mode_has_keypad(MODE) ? kDqWsMaxTiles * 8 : 0);
             p.nblk = (p.f.Sq + 127) / 128;
             constexpr auto kern = &fasn_bwd_dq_ws_kernel<Tag, D, MODE, DROP>;
@@ -54,6 +64,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
             dq_done = true;
         }
     }
+    if constexpr (ONE_WAVE) {
     if (!dq_done) {   // dQ
         constexpr int BM = 4 * QB * 32;
         constexpr int smem = 4 * KT * D * 2 + (mode_is_vector(MODE) ? 4 * QB * ((BF32 ? 8192 : 4096) + ((BF32 && !mode_has_vmask(MODE)) ? 0 : 2048)) : 0);   // + per-wave bias / mask images
@@ -65,8 +76,9 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
         p.f.pair = 0;
     }
+    }
     if (p.skip & 1) return launch_rc();
-    if constexpr (WS != 0 && MODE != MODE_GENERAL_SLOW && !mode_has_vmask(MODE)) {
+    if constexpr (WS_MODE) {
         if (!(FASN_BWD_VARIANT & 1) && (!DROP || p.f.kvg == 1)) {   // dK, dV: two cooperating waves per key block (dropout: one query head per K/V head)
             constexpr int smem = 6 * QT * D * 2 + 2 * 16384 + 6 * QT * 4 + (mode_has_vbias(MODE) ? 4 * 3 * 2048 : 0);
             p.nblk = (p.f.Sk + 127) / 128;
@@ -86,7 +98,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
             return launch_rc();
         }
     }
-    {   // dK, dV
+    if constexpr (ONE_WAVE) {   // dK, dV
         constexpr int BN = 4 * KB * 32;
         constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (mode_is_vector(MODE) ? 2 * QT * BN * (BF32 ? 4 : 2) : 0);
         p.nblk = (p.f.Sk + BN - 1) / BN;
@@ -120,12 +132,15 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
                 if (p.f.kvg == 1) return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, 1, 1, 1, WS>(p, s);
             }
         }
+        // D = 32: ONE 32-key block per wave in the dropout dK/dV kernels (round 6: with two, the causal / key-padding / grouped-K/V dropout
+        // instantiations spilled 1 - 72 registers at their 256; with one they need 149 - 167, no spill, and three waves per SIMD fit)
+        constexpr int KBD = D == 32 ? 1 : KB;
         switch (mode) {
-            case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K, 1, WS>(p, s);
-            case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K, 1, WS>(p, s);
-            case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_KEYPAD, OCC_Q, OCC_K, 1, WS>(p, s);
+            case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KBD, MODE_PLAIN, OCC_Q, OCC_K, 1, WS>(p, s);
+            case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KBD, MODE_CAUSAL, OCC_Q, OCC_K, 1, WS>(p, s);
+            case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KBD, MODE_KEYPAD, OCC_Q, OCC_K, 1, WS>(p, s);
             case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1, 1>(p, s);
-            default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 1>(p, s);   // vector mask / bias
+            default: return launch_bwd_one<Tag, D, QB, KBD, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 1>(p, s);   // vector mask / bias
         }
     }
     if constexpr (D <= 128) {   // fp32 bias next to 16-bit q / k / v on the vector path (fasn_api.hip: f32_bias_vector); D = 128: the ONE-wave kernels (the two-wave ones have no LDS left for 8 KiB images)

@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
     const int l31 = lane & 31;
     const int hi = lane >> 5;
     const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
+    const DropThr dthr = drop_thr(DROP ? p.drop_thr : 1u);
 
     int bh, kblk0;
     block_to_work((int)blockIdx.x, p.B * p.H, (causal && p.pair) ? (bp.nblk + 1) / 2 : bp.nblk, bh, kblk0);
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
     vec8 dot[2][DB], qt[2][DB];   // transposed fragments of the block whose G MFMAs come next
     vec8 pk[2], dsk[2];        // 16-bit P, dS of that block
     f32x16 xr;                 // DROP: -delta of the rows of the block whose element pass comes next
-    const DropLane dlane = drop_lane(key & 3);
+    const DropLane dlane = drop_lane(key);
 
     // The phases are cut into sched_barrier-delimited pieces so that the register allocator can time-share one 32-register block
     // between the row fragments (live from phase b of block j-1 to the S MFMAs of block j) and the transposed fragments (live from
@@ -234,15 +235,8 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
             const float pv = fast_exp2(s[r]);
             if (DROP) {
                 const int g = r >> 2;
-                const uint32_t own = drop_mix(drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)(r0 + 8 * g + 4 * hi + (lane & 3))), dsd.hi, (uint32_t)(key >> 2));   // (one per g: CSE)
-                uint32_t hy;
-                switch (r & 3) {   // quad_perm broadcast of lane (quad base + (r & 3)): the state of THIS register's row
-                    case 0: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0x00, 0xf, 0xf, false); break;
-                    case 1: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0x55, 0xf, 0xf, false); break;
-                    case 2: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xAA, 0xf, 0xf, false); break;
-                    default: hy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xFF, 0xf, 0xf, false); break;
-                }
-                const bool keep = drop_keep(drop_word(hy, dlane), p.drop_thr << 16);
+                const uint32_t own = drop_mix(drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)(r0 + 8 * g + 4 * hi + (lane & 3))), dsd.hi, (uint32_t)(key >> 4));   // (one per g: CSE)
+                const bool keep = (int32_t)drop_word(quad_bcast(own, r & 3), dlane) >= dthr.hi32;   // the state of THIS register's row, from the lane of the key quad that computed it
                 s[r] = keep ? pv : 0.f;                                             // what dV multiplies (its 1/(1-p) at the end)
                 pp[r] = pv * ((keep ? pp[r] * p.drop_scale : 0.f) + xr[r]);          // dS = P o (dropped dP - delta)
             } else {
@@ -915,6 +909,8 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
     };
     const float ndlt = -dlt;
     const uint32_t drop_rb = DROP ? drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row) : 0u;
+    const DropThr dthr = drop_thr(DROP ? p.drop_thr : 1u);
+    const uint32_t drop_rh = drop_rh_of(hi);
     auto mfma_P = [&]() __attribute__((always_inline)) {
         const f32x16 zero = {};
         pa = E::mfma(vf[0], dof[0], DROP ? zero : dseed);
@@ -928,13 +924,11 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
             for (int d = 0; d < DB; ++d) dqacc[d] = E::mfma(ktf[t2][d], dsf[t2], dqacc[d]);
     };
     auto exps = [&](f32x16& s, int k0) __attribute__((always_inline)) {   // (k0: first key of the block)
+        const DropBlock<false> db(drop_rb, dsd.hi, (uint32_t)(k0 >> 4), hi, drop_rh);   // DROP: the states of the lane's 16 weights of this block (fasn_common.h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float pv = fast_exp2(s[r]);
-            if (DROP) {   // registers 4g .. 4g+3 are one key quad (keys k0 + 8g + 4hi + 0..3): one state per quad, the word of key & 3 = r & 3
-                const uint32_t hy = drop_mix(drop_rb, dsd.hi, (uint32_t)((k0 + 8 * (r >> 2) + 4 * hi) >> 2));
-                pv = drop_keep(drop_word(hy, r & 3), p.drop_thr << 16) ? pv : -pv;
-            }
+            if (DROP) pv = db.keep(r, dthr) ? pv : -pv;   // (sign set = dropped: what mulpack reads)
             s[r] = pv;
         }
     };

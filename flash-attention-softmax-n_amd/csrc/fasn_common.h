@@ -203,11 +203,23 @@ FASN_DEV void retire_loads(V& v) {
 }
 
 // ---- dropout -------------------------------------------------------------------------------------------------------
-// Counter-based, layout-independent: the keep/drop decision of attention weight (bh, row i, key j) is a 16-bit field of a hash of
-// (seed, offset, bh, i, j >> 2) and j & 3; the weight is kept iff field >= thr (drop probability thr / 65536, so a
-// requested p is honoured to 1.5e-5). Every kernel (forward and both backward kernels, which hold the score tile in different
-// register layouts) recomputes the same bits. Mirror on the host: flash-attention-softmax-n_amd/dropout.py (the tests build
-// the explicit mask for the oracle with it).
+// Counter-based, layout-independent (stream definition 2, round 6): the keep/drop decision of attention weight (bh, row i, key j) is a
+// 16-bit field of a hash of (seed, offset, bh, i, j >> 4) and j & 15; the weight is kept iff field >= thr (drop probability thr / 65536, so a
+// requested p is honoured to 1.5e-5). Every kernel (forward and both backward kernels, which hold the score tile in different register
+// layouts) recomputes the same bits. Mirror on the host: flash-attention-softmax-n_amd/dropout.py (the tests build the explicit mask for
+// the oracle with it).
+//   state  y = drop_mix(row_base(seed_lo, bh, i), seed_hi, j >> 4)        one 32-bit state per (row, GROUP OF 16 KEYS)
+//   pair   p = (j & 15) >> 1 = 4 q + 2 h + c   (q = octet of the group, h = quad of the octet, c = pair of the quad)
+//   word   w = mul24(rotl(y, 16 h + 4 q + 5 c), kDropMul[2 q + c])          one 24-bit multiply per PAIR of keys
+//   field  f = (j & 1 ? w >> 16 : w & 0xffff) ^ 0x8000,  kept iff f >= thr   <=>  (int16) half >= (int16)(thr - 32768)
+// Round 5 had one state per key quad and one multiply per key (6.4 VALU instructions per weight in the forward, 13 per score with the
+// select): the state now serves 16 keys and a product both keys of a pair - its halves ARE the two fields - so the forward tests a
+// PACKED pair of weights with three packed 16-bit instructions (saturating subtract, arithmetic shift, and) instead of a compare and a
+// select per weight. The window rotation is additive in (h, q, c): a lane of the transposed accumulator layout, which holds the keys
+// 8 q + 4 hi + {0..3} of a group, rotates the state ONCE by 16 hi and uses compile-time rotations and multipliers from there on.
+// Statistics (tools/dropout_hash_stats.py): keep decisions of any two of a group's 16 keys (they share one 32-bit state: the window offsets
+// 16 / 4 / 5 are the ones whose worst pair stays in the 1 / sqrt(N) noise of 4 M states at p = 0.1 .. 0.9 - with 16 / 8 / 4 one pair
+// correlated at 6e-3), of adjacent rows / heads / seeds / offsets correlate below the noise of 4 M samples.
 // The (seed, offset) pair comes by value in the launch parameters or - when the caller passes a device pointer - from two
 // 64-bit words in device memory that a captured graph can advance between replays (fasn_rng_advance).
 struct DropSeed {
@@ -227,42 +239,150 @@ FASN_DEV DropSeed drop_seed(uint32_t seed_lo, uint32_t seed_hi, const uint64_t* 
 FASN_DEV uint32_t drop_row_base(uint32_t seed_lo, uint32_t bh, uint32_t row) {
     return (seed_lo ^ (bh * 0x9E3779B1u)) + row * 0x85EBCA77u;
 }
-// The hash itself uses only full-rate VALU operations: 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: low 24 bits of both
-// operands, low 32 bits of the product), rotates (v_alignbit_b32), adds and xors - a 32-bit v_mul_lo_u32 issues at a quarter of
-// that rate, and the round-2 hash (four of them per key quad) was most of what dropout cost. drop_mix: one 32-bit state per
-// (row, key quad); drop_word(y, e): the word of key e of the quad, an INDEPENDENT 24-bit multiply of its own window of the state,
-// whose HIGH 16 bits are the weight's field - so "field >= thr" is one unsigned compare of the whole word against thr << 16.
-// Statistics (tools/dropout_hash_stats.py): every input bit flips 7.9 of a field's 16 bits on average (worst case over the 86
-// input bits 7.85), keep decisions of adjacent keys / rows / heads / seeds / offsets correlate below 1e-3.
+// The hash uses only full-rate VALU operations: 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: low 24 bits of both operands, low 32
+// bits of the product), rotates (v_alignbit_b32), adds and xors - a 32-bit v_mul_lo_u32 issues at a quarter of that rate.
 FASN_DEV uint32_t rotl32(uint32_t x, uint32_t r) { return __builtin_amdgcn_alignbit(x, x, 32u - r); }
-FASN_DEV uint32_t drop_mix(uint32_t row_base, uint32_t seed_hi, uint32_t key_quad) {
-    uint32_t x = (row_base + __umul24(key_quad, 0x9E3779u)) ^ seed_hi;
+FASN_DEV uint32_t drop_mix(uint32_t row_base, uint32_t seed_hi, uint32_t key_group) {   // key_group = key >> 4
+    uint32_t x = (row_base + __umul24(key_group, 0x9E3779u)) ^ seed_hi;
     const uint32_t a = __umul24(x, 0xC2B2AFu), b = __umul24(rotl32(x, 20), 0x85EBCBu);
     uint32_t y = a + rotl32(b, 13);
     y ^= y >> 15;
     return y + rotl32(y, 9);
 }
-FASN_DEV uint32_t drop_word(uint32_t y, int e) {   // e = key & 3, a compile-time constant at most call sites
-    switch (e) {
-        case 0: return __umul24(y, 0x2C1B3Du);
-        case 1: return __umul24(rotl32(y, 24), 0x297A2Du);
-        case 2: return __umul24(rotl32(y, 12), 0x1B56C5u);
-        default: return __umul24(rotl32(y, 20), 0x7ED55Du);
-    }
+// kDropMul[2 q + c]
+constexpr uint32_t drop_mul_of(int i) { return i == 0 ? 0x2C1B3Du : i == 1 ? 0x297A2Du : i == 2 ? 0x1B56C5u : 0x7ED55Du; }
+// word of pair p = 4 q + 2 h + c (compile-time p): both fields of the keys 2 p and 2 p + 1 of the group
+template <int P>
+FASN_DEV uint32_t drop_pair_word(uint32_t y) {
+    constexpr int Q = P >> 2, H = (P >> 1) & 1, C = P & 1, R = 16 * H + 4 * Q + 5 * C;
+    return __umul24(R == 0 ? y : rotl32(y, (uint32_t)R), drop_mul_of(2 * Q + C));
 }
-// the same with a lane-dependent e (the dK/dV kernels: a lane owns one key): rotation and multiplier picked per lane, once
-struct DropLane {
-    uint32_t rot, mul;
+// the same from a state that is already rotated by 16 h (yh = rotl(y, 16 hi), once per state, where h is the lane's half-wave)
+template <int Q, int C>
+FASN_DEV uint32_t drop_pair_word_h(uint32_t yh) {
+    constexpr int R = 4 * Q + 5 * C;
+    return __umul24(R == 0 ? yh : rotl32(yh, (uint32_t)R), drop_mul_of(2 * Q + C));
+}
+// thresholds of a launch, derived once: t16 = thr - 32768 as int16 (the fields are compared as signed halves),
+//   hi32 = t16 << 16: the HIGH field of a word is kept iff (int32) word >= hi32 (the low half cannot change the answer)
+//   pk1  = both halves t16 - 1: sat_sub_i16(pk1, word) is negative in exactly the halves that are kept
+struct DropThr {
+    int32_t hi32;
+    int16_t t16;
+    uint32_t pk1;
 };
-FASN_DEV DropLane drop_lane(int e) {
+FASN_DEV DropThr drop_thr(uint32_t thr) {   // thr in [1, 65535]
+    DropThr t;
+    const int32_t s = (int32_t)thr - 32768;
+    t.t16 = (int16_t)s;
+    t.hi32 = (int32_t)((uint32_t)s << 16);
+    t.pk1 = ((uint32_t)(s - 1) & 0xffffu) * 0x10001u;
+    return t;
+}
+FASN_DEV bool drop_keep_hi(uint32_t word, const DropThr& t) { return (int32_t)word >= t.hi32; }          // odd key of the pair
+FASN_DEV bool drop_keep_lo(uint32_t word, const DropThr& t) { return (int16_t)(uint16_t)word >= t.t16; }  // even key of the pair
+template <int S>
+FASN_DEV bool drop_keep_half(uint32_t word, const DropThr& t) { return S ? drop_keep_hi(word, t) : drop_keep_lo(word, t); }
+// 0xffff in the halves of `word` that are kept, 0 in the dropped ones: and-ed onto a packed pair of 16-bit weights
+FASN_DEV uint32_t drop_keep_mask_pk(uint32_t word, const DropThr& t) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    s16x2 w, th;
+    __builtin_memcpy(&w, &word, 4);
+    __builtin_memcpy(&th, &t.pk1, 4);
+    const s16x2 d = __builtin_elementwise_sub_sat(th, w) >> (short)15;
+    uint32_t m;
+    __builtin_memcpy(&m, &d, 4);
+    return m;
+}
+// The keep bits of the 16 weights a lane of a row-owning kernel (forward, dQ) holds of one 32-key block, in both register layouts -
+//   plain        : register r = key 8 (r >> 2) + 4 hi + (r & 3) of the block: pairs (q = g & 1, h = hi, c) of the groups g >> 1 (g = r >> 2).
+//                  Each half-wave computes ONE of the block's two states and both get both through one v_permlane32_swap (all 64 lanes
+//                  must be active and construct the block together); the states are rotated once by 16 hi (rh = 32 - 16 hi, the alignbit
+//                  amount), the windows from there on are compile-time;
+//   key-permuted : register r = key 16 hi + r (vector mask / bias modes): the lane's 16 keys are the whole group 2 kb + hi.
+// group0 = first key of the block >> 4. Only the two states stay live: word(i) - the product whose halves are the fields of registers 2 i and
+// 2 i + 1 - is formed where it is used (i compile-time after unrolling).
+template <bool KPERM>
+struct DropBlock {
+    uint32_t st[2];
+    FASN_DEV DropBlock(uint32_t row_base, uint32_t seed_hi, uint32_t group0, int hi, uint32_t rh) {
+        const uint32_t own = drop_mix(row_base, seed_hi, group0 + (uint32_t)hi);
+        if constexpr (KPERM) {
+            st[0] = st[1] = own;
+        } else {
+            const auto both = __builtin_amdgcn_permlane32_swap(own, own, false, false);   // [0]: the lower half-wave's state (group0), [1]: the upper one's (group0 + 1)
+            st[0] = __builtin_amdgcn_alignbit(both[0], both[0], rh);                      // rotated left by 16 hi
+            st[1] = __builtin_amdgcn_alignbit(both[1], both[1], rh);
+        }
+    }
+    FASN_DEV uint32_t word(int i) const {   // i = r >> 1
+        if constexpr (KPERM) {
+            switch (i & 7) {
+                case 0: return drop_pair_word<0>(st[0]);
+                case 1: return drop_pair_word<1>(st[0]);
+                case 2: return drop_pair_word<2>(st[0]);
+                case 3: return drop_pair_word<3>(st[0]);
+                case 4: return drop_pair_word<4>(st[0]);
+                case 5: return drop_pair_word<5>(st[0]);
+                case 6: return drop_pair_word<6>(st[0]);
+                default: return drop_pair_word<7>(st[0]);
+            }
+        } else {
+            const uint32_t yh = st[(i >> 2) & 1];
+            switch (i & 3) {   // 2 q + c
+                case 0: return drop_pair_word_h<0, 0>(yh);
+                case 1: return drop_pair_word_h<0, 1>(yh);
+                case 2: return drop_pair_word_h<1, 0>(yh);
+                default: return drop_pair_word_h<1, 1>(yh);
+            }
+        }
+    }
+    FASN_DEV bool keep(int r, const DropThr& t) const { return (r & 1) ? drop_keep_hi(word(r >> 1), t) : drop_keep_lo(word(r >> 1), t); }
+    FASN_DEV uint32_t keep_mask_pk(int i, const DropThr& t) const { return drop_keep_mask_pk(word(i), t); }   // registers 2 i, 2 i + 1 as a packed pair
+};
+FASN_DEV uint32_t drop_rh_of(int hi) { return 32u - 16u * (uint32_t)hi; }
+
+// a lane-dependent key (the dK/dV kernels: a lane owns one key): rotation, multiplier and the shift that brings the key's field into
+// the high half of the word, picked per lane, once
+struct DropLane {
+    uint32_t rot, mul, sh;
+};
+FASN_DEV DropLane drop_lane(int key) {
+    const int p = (key & 15) >> 1, q = p >> 2, h = (p >> 1) & 1, c = p & 1, i = 2 * q + c;
     DropLane d;
-    d.rot = e == 0 ? 32u : e == 1 ? 24u : e == 2 ? 12u : 20u;   // (rotate by 32 = by 0)
-    d.mul = e == 0 ? 0x2C1B3Du : e == 1 ? 0x297A2Du : e == 2 ? 0x1B56C5u : 0x7ED55Du;
+    const int r = 16 * h + 4 * q + 5 * c;
+    d.rot = r == 0 ? 32u : (uint32_t)r;   // (alignbit by 32 - rot: rotate by 32 = by 0)
+    d.mul = i == 0 ? 0x2C1B3Du : i == 1 ? 0x297A2Du : i == 2 ? 0x1B56C5u : 0x7ED55Du;
+    d.sh = (key & 1) ? 0u : 16u;
     return d;
 }
-FASN_DEV uint32_t drop_word(uint32_t y, DropLane d) { return __umul24(__builtin_amdgcn_alignbit(y, y, 32u - d.rot), d.mul); }
-// keep iff field >= thr (drop probability thr / 65536); thr16 = thr << 16
-FASN_DEV bool drop_keep(uint32_t word, uint32_t thr16) { return word >= thr16; }
+// the lane's field of state y, moved into the high half: kept iff (int32) result >= DropThr::hi32
+FASN_DEV uint32_t drop_word(uint32_t y, DropLane d) { return __umul24(__builtin_amdgcn_alignbit(y, y, 32u - d.rot), d.mul) << d.sh; }
+// In the dK/dV kernels a lane owns a KEY and its 16 registers of a block are 16 ROWS - (r & 3) + 8 (r >> 2) + 4 hi - so the state of
+// (row, key group) would be needed once per weight. The four lanes of a key quad (same group) hold the same rows: each computes the state of
+// ONE row of every 4-row register group (row 8 g + 4 hi + (lane & 3)) and the quad exchanges them with DPP quad_perm broadcasts.
+FASN_DEV uint32_t quad_bcast(uint32_t v, int i) {   // the value of lane (quad base + i); i is a compile-time constant at every call site
+    switch (i & 3) {
+        case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xf, 0xf, false);
+        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xf, 0xf, false);
+        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xf, 0xf, false);
+        default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xf, 0xf, false);
+    }
+}
+// own[g] = state of row row0 + 8 g + 4 hi + (lane & 3) and this lane's key group (row0: first row of the 32-row block)
+FASN_DEV void drop_quad_states(uint32_t (&own)[4], uint32_t seed_lo, uint32_t seed_hi, uint32_t bh, int row0, int hi, int lane, int key) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) own[g] = drop_mix(drop_row_base(seed_lo, bh, (uint32_t)(row0 + 8 * g + 4 * hi + (lane & 3))), seed_hi, (uint32_t)(key >> 4));
+}
+// kept? - weight (register r of the block, this lane's key)
+FASN_DEV bool drop_keep_quad(const uint32_t (&own)[4], int r, const DropLane& dl, const DropThr& t) {
+    return (int32_t)drop_word(quad_bcast(own[r >> 2], r & 3), dl) >= t.hi32;
+}
+// one weight, everything at run time (element-load and fp32 kernels)
+FASN_DEV bool drop_keep_at(const DropSeed& dsd, uint32_t bh, uint32_t row, uint32_t key, uint32_t thr) {
+    const uint32_t y = drop_mix(drop_row_base(dsd.lo, bh, row), dsd.hi, key >> 4);
+    return (int32_t)drop_word(y, drop_lane((int)key)) >= drop_thr(thr).hi32;
+}
 
 FASN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 

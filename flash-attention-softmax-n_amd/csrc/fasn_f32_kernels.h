@@ -77,11 +77,17 @@ struct GenElem {
         return mask ? mask[(int64_t)row * p.ms[2] + (int64_t)key * p.ms[3]] != 0 : true;
     }
 };
-FASN_DEV bool f32_keep(const FwdParams& p, int bh, int row, int key) {
-    const DropSeed dsd = drop_seed(p.seed_lo, p.seed_hi, p.rng);
-    const uint32_t y = drop_mix(drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row), dsd.hi, (uint32_t)(key >> 2));
-    return drop_keep(drop_word(y, drop_lane(key & 3)), p.drop_thr << 16);
-}
+// dropout of the fp32 kernels: the launch's seed pair and thresholds, read once per kernel; one weight at a time (fasn_common.h: drop_keep_at)
+struct F32Drop {
+    DropSeed dsd;
+    uint32_t thr;
+    FASN_DEV explicit F32Drop(const FwdParams& p) : dsd(p.drop_thr ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u}), thr(p.drop_thr ? p.drop_thr : 1u) {}
+#ifdef FASN_F32_NODROP
+    FASN_DEV bool keep(int, int, int) const { return true; }
+#else
+    FASN_DEV bool keep(int bh, int row, int key) const { return drop_keep_at(dsd, (uint32_t)bh, (uint32_t)row, (uint32_t)key, thr); }
+#endif
+};
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int D, int MODE>
@@ -96,6 +102,7 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
     int bh, qi;
     block_to_work(blockIdx.x, p.B * p.H, p.nqblk, bh, qi);
     constexpr bool GEN = MODE == MODE_GENERAL_SLOW;
+    const F32Drop fdrop(p);
     const bool causal = MODE == MODE_CAUSAL || (GEN && p.causal);
     const int qblk = causal ? (p.nqblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
@@ -182,8 +189,15 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
             for (int r = 0; r < 16; ++r) {
                 sacc[kb][r] = fast_exp2(sacc[kb][r] - m_use);
                 rs += sacc[kb][r];   // the row sum keeps the undropped weights
-                if (GEN && p.drop_thr && !f32_keep(p, bh, row, k0 + kb * 32 + acc_row(r, hi))) sacc[kb][r] = 0.f;
             }
+        if (GEN && p.drop_thr) {   // (a pass of its own behind a wave-uniform branch: with the hash inside the element loop above hipcc 7.2 miscompiled the
+                                   // p = 0 path of the D = 64 instantiation - garbage in the rows of a ragged last query block, round 6)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!fdrop.keep(bh, row, k0 + kb * 32 + acc_row(r, hi))) sacc[kb][r] = 0.f;
+        }
         l_run = l_run * alpha + rs;
         m_run = m_new;
         if (!__all(alpha == 1.0f)) {
@@ -259,6 +273,7 @@ __global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
     int bh, qi;
     block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
     constexpr bool GEN = MODE == MODE_GENERAL_SLOW;
+    const F32Drop fdrop(bp.f);
     const bool causal = MODE == MODE_CAUSAL || (GEN && p.causal);
     const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
@@ -344,7 +359,7 @@ __global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
                 float pv = fast_exp2(y - lse2);
                 pv = show ? pv : 0.f;
                 float dp = pacc[kb][r];
-                if (GEN && p.drop_thr) dp = f32_keep(p, bh, row, key) ? dp * p.drop_scale : 0.f;
+                if (GEN && p.drop_thr) dp = fdrop.keep(bh, row, key) ? dp * p.drop_scale : 0.f;
                 sacc[kb][r] = pv * (dp - dlt);   // dS^T (without the scale factor)
                 if (GEN && bp.dbias != nullptr && ok && key < p.Sk)
                     reinterpret_cast<float*>(bp.dbias)[b * bp.dbs[0] + h * bp.dbs[1] + (int64_t)row * bp.dbs[2] + key] = sacc[kb][r];
@@ -394,6 +409,7 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
     int bhk, kblk;
     block_to_work(blockIdx.x, p.B * Hkv, bp.nblk, bhk, kblk);
     constexpr bool GEN = MODE == MODE_GENERAL_SLOW;
+    const F32Drop fdrop(bp.f);
     const bool causal = MODE == MODE_CAUSAL || (GEN && p.causal);
     const int b = bhk / Hkv, hk = bhk % Hkv;
     const int kw0 = kblk * BN + wave * 32, key = kw0 + l31, coff = p.Sk - p.Sq;
@@ -490,6 +506,13 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
                     pacc = mfma32(da[e], vf[c][e], pacc);   // dP[q][key]
                 }
             }
+            // dropout in passes of their own behind a wave-uniform branch (see the forward): dP is dropped and scaled in front of the element
+            // pass, the weights that feed dV behind it (dS uses the undropped P); the keep bits are computed twice - the fp32 dropout path is
+            // the reference's test grid, not a hot path
+            if (GEN && p.drop_thr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pacc[r] *= fdrop.keep(bh, r0 + qb * 32 + acc_row(r, hi), key) ? p.drop_scale : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = qb * 32 + acc_row(r, hi);
@@ -499,14 +522,12 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
                 if (GEN && show) show = ge.apply(p, row, key, y);
                 float pv = fast_exp2(y - tL[rr]);
                 pv = show ? pv : 0.f;
-                float dp = pacc[r], pd = pv;
-                if (GEN && p.drop_thr) {
-                    const bool keep = f32_keep(p, bh, row, key);
-                    dp = keep ? dp * p.drop_scale : 0.f;
-                    pd = keep ? pv * p.drop_scale : 0.f;
-                }
-                sacc[r] = pd;                      // dropped weights feed dV
-                pacc[r] = pv * (dp - tX[rr]);      // dS uses the undropped P
+                sacc[r] = pv;
+                pacc[r] = pv * (pacc[r] - tX[rr]);      // dS uses the undropped P
+            }
+            if (GEN && p.drop_thr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] *= fdrop.keep(bh, r0 + qb * 32 + acc_row(r, hi), key) ? p.drop_scale : 0.f;   // dropped weights feed dV
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)

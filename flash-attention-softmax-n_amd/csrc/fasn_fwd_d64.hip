@@ -83,7 +83,11 @@ static int dev_variant(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 #endif
 template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
-    if (p.drop_thr) return launch_fwd_drop<Tag, 64, 1, 2>(p, l.mode, s);   // (round 4: 64 rows per wave spills 37-67 registers with the hash, three waves per SIMD 26-30)
+    if (p.drop_thr) {   // dropout: the plain kernels' tuning points (round 6: the keep bits are applied to the packed weights - no spills at 64 rows per wave)
+        const long bq2 = (long)((p.Sq + 255) / 256) * p.B * p.H;
+        const bool big = (l.mode == MODE_PLAIN || (l.mode == MODE_KEYPAD && !p.causal)) && bq2 >= 512 && p.Sq >= 256;
+        return big ? launch_fwd_drop<Tag, 64, 2, 2>(p, l.mode, s) : launch_fwd_drop<Tag, 64, 1, 3>(p, l.mode, s);
+    }
     if (l.mode >= MODE_GENERAL && l.mode != MODE_KEYPAD) return launch_gen<Tag>(p, l, s);   // key-padding masks ride the plain tuning points
     // auto (what ABI callers get), measured on MI355X at (8,16,4096,64), 200 launches each. All plain / causal / key-padding
     // kernels run with seeded accumulators (Q pre-scaled, S starts at -m, row sums by v_dot2c on the packed weights):

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     static_assert(VH == 1 || (VH == 2 && !SPLIT), "feature halves: not with split-K");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
-    constexpr bool PSUM = SEED >= 2 && !DROP;   // fast-path row sums from the packed weights
+    constexpr bool PSUM = SEED >= 2;   // fast-path row sums from the packed weights (dropout masks the packed weights AFTER the sum)
     constexpr bool UNR3 = RING == 2 && (D <= 64 || (FASN_UNR3_D128 && NW == 8 && !mode_is_vector(MODE) && !DROP));  // direct-to-LDS loop unrolled by its three buffers
     constexpr bool UNR2 = RING == 0 && FASN_FWD_UNR2;   // single-set staging: loop unrolled by its two LDS buffers
     constexpr int NT = NW * 64;
@@ -467,6 +467,8 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     };
 
     const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
+    const DropThr dthr = drop_thr(DROP ? p.drop_thr : 1u);
+    const uint32_t drop_rh = drop_rh_of(hi);   // alignbit amount of "rotate left by 16 hi"
     // ---- online-softmax state, per lane = per query row (log2 domain: y = x * log2(e))
     float m_run[QB], l_run[QB];
     f32x16 oacc[QB][DB];
@@ -831,18 +833,18 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
 #endif
             if (PRIO == 3 && NW == 4) __builtin_amdgcn_s_setprio(0);
 
-            // dropout of the 8 weights of (qb, kb, t2): keys k0 + kb*32 + 16*t2 + 4*hi + {0..3} and + 8 + {0..3}
-            auto drop8 = [&](f32x8& x, int qb, int kb, int t2) {
-                const uint32_t rb = drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)(qw0 + qb * 32 + l31));
-                // registers 8*t2 + {0..3} and + {4..7} are two groups of 4 consecutive keys: 8 apart in the plain layout,
-                // adjacent in the key-permuted layout of the vector general modes
-                const uint32_t kq = (uint32_t)((k0 + kb * 32 + (KPERM ? 16 * hi + 8 * t2 : 16 * t2 + 4 * hi)) >> 2);
-                const uint32_t y0 = drop_mix(rb, dsd.hi, kq), y1 = drop_mix(rb, dsd.hi, kq + (KPERM ? 1 : 2));
-                const uint32_t thr16 = p.drop_thr << 16;
+            // dropout of the 16 packed weights of (qb, kb), applied to the PACKED pairs (stream definition 2, fasn_common.h: DropBlock):
+            // three packed 16-bit instructions per pair instead of a compare and a select per weight
+            vec8 pf[QB][2][2];  // [qb][kb][t]: B operand of the PV MFMA
+            auto drop_pack = [&](int qb, int kb) {
+                const DropBlock<KPERM> db(drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)(qw0 + qb * 32 + l31)), dsd.hi, (uint32_t)((k0 + kb * 32) >> 4), hi, drop_rh);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    x[e] = drop_keep(drop_word(y0, e), thr16) ? x[e] : 0.f;
-                    x[4 + e] = drop_keep(drop_word(y1, e), thr16) ? x[4 + e] : 0.f;
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    uint32_t w[4];
+                    __builtin_memcpy(w, &pf[qb][kb][t2], 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] &= db.keep_mask_pk(4 * t2 + e, dthr);   // dword e of t2 = registers 8 t2 + 2 e, + 1
+                    __builtin_memcpy(&pf[qb][kb][t2], w, 16);
                 }
             };
 
@@ -851,7 +853,6 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
             // the tile max first; the result is exact as long as nothing overflows, which the row sum itself reveals
             // (any p > 2^8, an unset max (-inf) or a NaN makes the lane's partial sum exceed kSumLimit / compare false).
             // Only then - wave-uniformly - is the tile redone on the exact path, which re-centres the max.
-            vec8 pf[QB][2][2];  // [qb][kb][t]: B operand of the PV MFMA
 #pragma unroll
             for (int qb = QLO; qb < QHI; ++qb) {
                 bool exact = (FOLD ? maskq[qb] : need_mask) || (SEED && unseeded);   // (non-FOLD kernels: the wave-level flag itself - through the per-block array the split-K mask / bias kernel lost the uniform branch and 100 registers)
@@ -879,7 +880,6 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                                     x[e + 1] = pv[1];
                                     if (!PSUM) rs2 += pv;
                                 }
-                                if (DROP) drop8(x, qb, kb, t2);   // the row sum keeps the undropped weights
                                 pf[qb][kb][t2] = E::cvt8(x);
                                 if (PSUM) {   // row sum of the ROUNDED weights (what the PV MFMA multiplies), two per instruction
                                     uint32_t w[4];
@@ -982,7 +982,6 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                                 x[e] = fast_exp2(sacc[qb][kb][8 * t2 + e] - m_sub);
                                 rs += x[e];
                             }
-                            if (DROP) drop8(x, qb, kb, t2);
                             pf[qb][kb][t2] = E::cvt8(x);
                         }
                     l_run[qb] = l_run[qb] * alpha + rs;
@@ -998,6 +997,12 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
                             for (int r = 0; r < 16; ++r) oacc[qb][d][r] *= alpha;
                     }
                 }
+            }
+            if constexpr (DROP != 0) {   // the row sums above are those of the undropped weights (LSE is dropout-free)
+#pragma unroll
+                for (int qb = QLO; qb < QHI; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) drop_pack(qb, kb);
             }
             if (SEED && unseeded) {   // rows that saw only hidden keys so far keep the wave on the exact path
                 bool u = false;

@@ -125,40 +125,37 @@ int launch_fwd_cfg(const FwdParams& p, int mode, hipStream_t s) {
     return launch_fwd_one<Tag, D, QB, MODE_CAUSAL, OCC, NW, RING, SEED>(p, s);
 }
 
-#ifndef FASN_DROP_8WAVE
-#define FASN_DROP_8WAVE 1
-#endif
-#ifndef FASN_DROP_RING
-#define FASN_DROP_RING 2   // staging scheme of the plain / causal / key-padding dropout kernels (0 = register-staged, 2 = direct-to-LDS)
-#endif
 // dropout instantiations: plain, causal, key-padding, the vector mask / bias kernel (MODE_GENERAL serves all three mask / bias
 // combinations: an absent operand is a zero-range descriptor / an all-ones word) and the element-load general kernel.
-// Seeded S accumulators; the row sums stay fp32 (taken before the drop).
+// Round 6 (dropout stream definition 2, fasn_common.h): the keep bits are applied to the PACKED weights, behind the row sums - the dropout
+// kernels run at the plain kernels' tuning points, seeded accumulators and packed row sums (SEED = 2) included: 64 rows per wave at D = 64 no
+// longer spill (244 registers; the round-5 hash needed 37 - 67 more), three waves per SIMD fit in 144.
+// QB / OCC: the tuning point of the plain kernel for this launch (fasn_fwd_d*.hip decides by the size of the grid).
 template <typename Tag, int D, int QB, int OCC>
 int launch_fwd_drop(const FwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_BIAS_KEYPAD) {
         // vector bias + key-padding mask (ALiBi on a padded batch) with dropout: the visibility-word kernel at D = 128 (round 4), elsewhere
         // the dense-mask general mode of the same mask
-        if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_BIAS_KEYPAD, 2, 8, 2, 1, 1>(p, s);
+        if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_BIAS_KEYPAD, 2, 8, 2, 2, 1>(p, s);
         else mode = p.keypad_fallback;
     }
     if (mode == MODE_PLAIN) {
-        if constexpr (D == 128 && FASN_DROP_8WAVE) return launch_fwd_one<Tag, D, 1, MODE_PLAIN, 2, 8, 2, 1, 1>(p, s);   // 8 waves share a K/V tile, two per SIMD
-        else return launch_fwd_one<Tag, D, QB, MODE_PLAIN, OCC, 4, FASN_DROP_RING, 1, 1>(p, s);
+        if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_PLAIN, 2, 8, 2, 2, 1>(p, s);   // 8 waves share a K/V tile, two per SIMD
+        else return launch_fwd_one<Tag, D, QB, MODE_PLAIN, OCC, 4, 2, 2, 1>(p, s);
     }
     if (mode == MODE_CAUSAL) {
-        if constexpr (D == 128 && FASN_DROP_8WAVE) return launch_fwd_one<Tag, D, 1, MODE_CAUSAL, 2, 8, 2, 1, 1>(p, s);   // 8 waves share a K/V tile, two per SIMD
-        else return launch_fwd_one<Tag, D, QB, MODE_CAUSAL, OCC, 4, FASN_DROP_RING, 1, 1>(p, s);
+        if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_CAUSAL, 2, 8, 2, 2, 1>(p, s);
+        else return launch_fwd_one<Tag, D, QB, MODE_CAUSAL, OCC, 4, 2, 2, 1>(p, s);
     }
     if (mode == MODE_KEYPAD) {
-        if constexpr (D == 128 && FASN_DROP_8WAVE) return launch_fwd_one<Tag, D, 1, MODE_KEYPAD, 2, 8, 2, 1, 1>(p, s);   // 8 waves share a K/V tile, two per SIMD
-        else return launch_fwd_one<Tag, D, QB, MODE_KEYPAD, OCC, 4, FASN_DROP_RING, 1, 1>(p, s);
+        if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_KEYPAD, 2, 8, 2, 2, 1>(p, s);
+        else return launch_fwd_one<Tag, D, QB, MODE_KEYPAD, OCC, 4, 2, 2, 1>(p, s);
     }
     if (mode == MODE_GENERAL || mode == MODE_GENERAL_B || mode == MODE_GENERAL_M) {
-        if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_GENERAL, 2, 8, 2, 1, 1>(p, s);
-        else return launch_fwd_one<Tag, D, 1, MODE_GENERAL, (D == 32 ? 1 : 2), 4, 0, 1, 1>(p, s);
+        if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_GENERAL, 2, 8, 2, 2, 1>(p, s);
+        else return launch_fwd_one<Tag, D, (D == 32 ? 2 : 1), MODE_GENERAL, (D == 32 ? 1 : 2), 4, 0, 2, 1>(p, s);   // (the p = 0 vector kernels' tuning points)
     }
-    return launch_fwd_one<Tag, D, QB, MODE_GENERAL_SLOW, 1, 4, 0, 0, 1>(p, s);
+    return launch_fwd_one<Tag, D, (D == 32 ? 2 : 1), MODE_GENERAL_SLOW, 1, 4, 0, 0, 1>(p, s);
 }
 
 #ifdef FASN_DEV_VARIANTS

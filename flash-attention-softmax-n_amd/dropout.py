@@ -1,10 +1,14 @@
-"""Host mirror of the kernels' dropout bits (csrc/fasn_common.h: drop_seed / drop_row_base / drop_mix / drop_word / drop_keep).
+"""Host mirror of the kernels' dropout bits (csrc/fasn_common.h: drop_seed / drop_row_base / drop_mix / drop_pair_word / DropThr).
 
-The keep/drop decision of attention weight (b, h, row i, key j): y = drop_mix(row_base(seed, offset, b*H + h, i), seed_hi, j >> 2), a
-32-bit state built from 24-bit multiplies, rotates, adds and xors (full-rate VALU operations only); word = drop_word(y, j & 3), one more
-24-bit multiply of a window of y that depends on j & 3; kept iff (word >> 16) >= thr, thr = round(65536 p) clipped to [1, 65535]
-(p honoured to 1.5e-5). Used by the tests to build the explicit mask for the oracle, and by anyone who needs to reproduce a run's
-dropout pattern.
+Stream definition 2 (round 6). The keep/drop decision of attention weight (b, h, row i, key j):
+  y    = drop_mix(row_base(seed, offset, b*H + h, i), seed_hi, j >> 4)      one 32-bit state per (row, group of 16 keys), built from 24-bit
+                                                                           multiplies, rotates, adds and xors (full-rate VALU operations only)
+  p    = (j & 15) >> 1 = 4 q + 2 h + c                                      the key's pair inside the group
+  word = mul24(rotl(y, 16 h + 4 q + 5 c), MUL[2 q + c])                     one more 24-bit multiply per PAIR of keys
+  f    = (word >> 16 if j & 1 else word & 0xffff) ^ 0x8000                  the odd key's field is the high half of the product, the even key's the low half
+  kept iff f >= thr, thr = round(65536 p) clipped to [1, 65535] (p honoured to 1.5e-5).
+(Round 5 used one state per key quad and one multiply per key; the kernels of round 6 test a packed pair of weights with three packed
+16-bit instructions.) Used by the tests to build the explicit mask for the oracle, and by anyone who needs to reproduce a run's dropout pattern.
 """
 import numpy as np
 
@@ -42,14 +46,15 @@ def keep_mask(seed: int, offset: int, B: int, H: int, L: int, S: int, p: float) 
         r = np.uint64(r)
         return ((u << r) | (u >> (np.uint64(32) - r))) & _M32
 
-    x = ((rb + mul24(key >> np.uint64(2), 0x9E3779)) & _M32) ^ seed_hi
+    x = ((rb + mul24(key >> np.uint64(4), 0x9E3779)) & _M32) ^ seed_hi
     y = (mul24(x, 0xC2B2AF) + rotl(mul24(rotl(x, 20), 0x85EBCB), 13)) & _M32
     y ^= y >> np.uint64(15)
     y = (y + rotl(y, 9)) & _M32
-    e = key & np.uint64(3)
-    rot = np.choose(e.astype(np.int64), [np.uint64(32), np.uint64(24), np.uint64(12), np.uint64(20)])
-    mul = np.choose(e.astype(np.int64), [np.uint64(0x2C1B3D), np.uint64(0x297A2D), np.uint64(0x1B56C5), np.uint64(0x7ED55D)])
-    win = np.where(rot == np.uint64(32), y, ((y << rot) | (y >> (np.uint64(32) - rot))) & _M32)
+    pr = ((key & np.uint64(15)) >> np.uint64(1)).astype(np.int64)            # pair p = 4 q + 2 h + c
+    q, hh, c = pr >> 2, (pr >> 1) & 1, pr & 1
+    rot = (16 * hh + 4 * q + 5 * c).astype(np.uint64)
+    mul = np.choose(2 * q + c, [np.uint64(0x2C1B3D), np.uint64(0x297A2D), np.uint64(0x1B56C5), np.uint64(0x7ED55D)])
+    win = np.where(rot == np.uint64(0), y, ((y << rot) | (y >> (np.uint64(32) - np.where(rot == 0, np.uint64(1), rot)))) & _M32)
     word = ((win & m24) * mul) & _M32
-    field = word >> np.uint64(16)
+    field = np.where((key & np.uint64(1)) == np.uint64(1), word >> np.uint64(16), word & np.uint64(0xFFFF)) ^ np.uint64(0x8000)
     return (field >= np.uint64(thr)).reshape(B, H, L, S)

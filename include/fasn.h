@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FASN_ABI_VERSION 5
+#define FASN_ABI_VERSION 6
 
 /* error codes */
 #define FASN_OK 0
@@ -177,12 +177,15 @@ size_t fasn_bwd_workspace_bytes(const fasn_bwd_args* args);
 int fasn_bwd(const fasn_bwd_args* args, fasn_stream_t stream);
 
 /*
- * The launches behind a call (ABI 5; diagnostic like fasn_fwd_path, no counterpart in the reference, whose launch sites are
+ * The launches behind a call (ABI 5, the cfg field ABI 6; diagnostic like fasn_fwd_path, no counterpart in the reference, whose launch sites are
  * flash_attention_softmax_n/core/flash_attn_triton.py:278-291,316-335): runs the host side of fasn_fwd (FASN_PLAN_FWD, reads only
  * args->fwd), fasn_bwd (FASN_PLAN_BWD) or fasn_fwd_ws with the workspace it asks for (FASN_PLAN_FWD_WS) on `args` with every launch
  * site recording instead of launching, and writes one line per kernel into `buf`:
- *     "kernel_name<template arguments> grid=G block=T lds=L\n"
- * (NUL-terminated). No kernel runs, no device memory is touched, no HIP call is made - pointers in `args` only have to be
+ *     "kernel_name<template arguments> grid=G block=T lds=L cfg=C\n"
+ * (NUL-terminated; ABI 6: C names the template arguments of the kernel family - "bf16,D=64,QB=2,plain,OCC=2,NW=4,RING=2,SEED=2" for
+ * fasn_fwd_kernel<fasn::bf16_tag, 64, 2, 0, 2, 4, 0, 0, 2, 0, 2, 1, 0, 0>: element type, head dim, 32-row blocks per wave, mode, waves per
+ * SIMD the kernel is compiled for, waves per workgroup, K/V staging scheme, accumulator seeding; flags that are off are left out; "-" for a
+ * kernel without a table - so that a plan, a profile line or a spill table reads without the kernel headers open). No kernel runs, no device memory is touched, no HIP call is made - pointers in `args` only have to be
  * non-NULL and aligned as for the real call. Returns the number of bytes written (without the NUL), the FASN_E* code the real
  * call would return, or FASN_EINVAL when `cap` is too small. The names are those of the code objects inside the library, so a
  * profile (rocprofv3 --kernel-trace) and a register / spill table (llvm-readelf on the bundle) can be matched against them.

@@ -41,7 +41,7 @@ def test_library_exports_nothing_but_the_header(pkg):
 
 def test_abi_version_and_strerror(pkg):
     lib = pkg._lib.load()
-    assert lib.fasn_abi_version() == 5
+    assert lib.fasn_abi_version() == 6
     assert lib.fasn_strerror(0) == b"ok"
     for code in range(-8, 0):
         assert len(lib.fasn_strerror(code)) > 5
@@ -113,6 +113,15 @@ def test_launch_plan_names_the_kernels_of_the_baseline_configs(pkg):
     c4b = [k[0].split("<")[0] for k in kernels(pkg, "c4", "bwd")]
     assert c4b == ["fasn_bwd_delta_kernel", "fasn_bwd_dq_ws_kernel", "fasn_bwd_dkdv_ws_kernel"]
     assert [k[0].split("<")[0] for k in kernels(pkg, "c1", "fwd")] == ["fasn_f32_fwd_kernel"]
+    # ABI 6: the cfg field names the positional template arguments (what bench.py prints and a reader of a profile wants)
+    from baseline_plans import bwd_args as _ba
+    d = lambda cfg, which: [k[0] for k in pkg._lib.launch_plan_described(_ba(pkg, cfg), which)]
+    assert d("m0", pkg._lib.FASN_PLAN_FWD) == ["fasn_fwd_kernel<bf16,D=64,QB=2,plain,OCC=2,NW=4,RING=2,SEED=2>"]
+    assert d("m0", pkg._lib.FASN_PLAN_BWD) == ["fasn_bwd_dq_pipe_kernel<bf16,plain>", "fasn_bwd_dkdv_pipe_kernel<bf16,plain>"]
+    assert d("c4", pkg._lib.FASN_PLAN_FWD) == ["fasn_fwd_kernel<bf16,D=128,QB=1,bias+keypad,OCC=2,NW=8,RING=2,SEED=2>"]
+    assert d("c4", pkg._lib.FASN_PLAN_BWD) == ["fasn_bwd_delta_kernel<bf16,D=128>", "fasn_bwd_dq_ws_kernel<bf16,D=128,bias+keypad>", "fasn_bwd_dkdv_ws_kernel<bf16,D=128,bias+keypad>"]
+    assert d("c3", pkg._lib.FASN_PLAN_FWD) == ["fasn_fwd_kernel<f16,D=64,QB=2,causal,OCC=2,NW=4,RING=2,SEED=2,FOLD=1>"]
+    assert d("c1", pkg._lib.FASN_PLAN_FWD) == ["fasn_f32_fwd_kernel<D=32,plain>"]
     # errors come back as the real call's code; a buffer that is too small is an argument error, not a truncated list
     import ctypes
     from baseline_plans import bwd_args
@@ -233,8 +242,10 @@ def test_dropout_host_mirror_statistics(pkg):
 
 
 def test_dropout_keep_bits_of_neighbours_are_independent(pkg):
-    """the four fields of a key quad come from independent multiplies of the (row, quad) state: keep decisions of adjacent keys,
-    adjacent rows, neighbouring heads, seeds and offsets must not correlate (|r| < 4 sigma of the sample), at several rates"""
+    """Stream definition 2 (round 6, csrc/fasn_common.h): the 16 fields of a 16-key group are the halves of eight 24-bit multiplies of rotated
+    windows of ONE (row, group) state. Keep decisions of adjacent keys, of any two positions of a group, of adjacent rows, neighbouring heads,
+    seeds and offsets must not correlate (|r| < 4 sigma of the sample; for the 120 position pairs of a group < 4.5 sigma: the maximum of 120
+    draws), at several rates; the realised rate is the requested one."""
     import numpy as np
     d = pkg.dropout
     L = S = 768
@@ -243,9 +254,26 @@ def test_dropout_keep_bits_of_neighbours_are_independent(pkg):
         K = d.keep_mask(2024, 3, 1, 2, L, S, p)[0].astype(np.float64)
         c = lambda a, b: abs(float(np.corrcoef(a.ravel(), b.ravel())[0, 1]))
         assert abs((1 - K.mean()) - d.effective_p(p)) < 4 * np.sqrt(p * (1 - p) / K.size)
-        for shift in (1, 2, 3, 4):
+        for shift in (1, 2, 3, 4, 8, 15, 16):
             assert c(K[..., :-shift], K[..., shift:]) < 4 * sigma, (p, "key", shift)
+        for shift in (1, 2, 3, 4):
             assert c(K[:, :-shift], K[:, shift:]) < 4 * sigma, (p, "row", shift)
         assert c(K[0], K[1]) < 6 * sigma
         assert c(K, d.keep_mask(2025, 3, 1, 2, L, S, p)[0].astype(np.float64)) < 4 * sigma
         assert c(K, d.keep_mask(2024, 4, 1, 2, L, S, p)[0].astype(np.float64)) < 4 * sigma
+        G = K.reshape(2, L, S // 16, 16)
+        n = 2 * L * (S // 16)
+        worst = max((c(G[..., a], G[..., b]) * np.sqrt(n), a, b) for a in range(16) for b in range(a + 1, 16))
+        assert worst[0] < 4.5, (p, "positions of a 16-key group", worst)
+
+
+def test_dropout_host_mirror_known_answer(pkg):
+    """The stream definition pinned by value: a change of the hash (window offsets, multipliers, which half of a product belongs to which
+    key) must be a deliberate one - the kernels are checked against THIS mirror on the GPU (tests/test_gpu_parity.py: dropout with the
+    explicit mask through the oracle)."""
+    import hashlib
+    import numpy as np
+    K = pkg.dropout.keep_mask(0x123456789ABCDEF, 42, 2, 3, 5, 40, 0.25)
+    assert K.shape == (2, 3, 5, 40)
+    digest = hashlib.sha256(np.packbits(K.reshape(-1, 40), axis=1).tobytes()).hexdigest()
+    assert digest == "14ea1d81b8ebedf25c6dc003b3153b876e544f1598278ae2b40263bf71c1fdf9", digest
