@@ -211,7 +211,9 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
     const int stid = tid - 256;
     auto stats_gload = [&](int row0) {
         if (stid >= 0 && stid < QT) {
-            const int gr = row0 + stid;
+            // (the row index from a FRESH lane id: formed from the lane id of the kernel entry, base + 4 * lane is loop invariant, the compiler keeps
+            // the two 64-bit addresses live across the tile loop - and, in the grouped-K/V walk, parks them in scratch and reloads them per tile)
+            const int gr = row0 + (GQA ? fresh_lane_id() + (wave - 4) * 64 : stid);   // (only where it pays: the plain instantiations answered with 4 spilled registers)
             float l = INFINITY, x = 0.f;
             if (gr < p.Sq) {
                 l = lsebase[gr];
@@ -595,13 +597,15 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
         else run(std::integral_constant<int, 1>{});
     }
 
-    // ---- epilogue: A writes dV, B writes dK * scale
-    if (key < p.Sk) {
-        char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + hk * bp.dvs[1] + (int64_t)key * bp.dvs[2]) * 2     // dK / dV are [B, H / kvg, Sk, D]
-                             : bp.dk + (b * bp.dks[0] + hk * bp.dks[1] + (int64_t)key * bp.dks[2]) * 2;
+    // ---- epilogue: A writes dV, B writes dK * scale (the output row address from a fresh lane id: nothing of it is live across the tile loop)
+    const int lane_e = GQA ? fresh_lane_id() : lane;
+    const int key_e = kw0 + (lane_e & 31), hi_e = lane_e >> 5;
+    if (key_e < p.Sk) {
+        char* rp = role == 0 ? bp.dv + (b * bp.dvs[0] + hk * bp.dvs[1] + (int64_t)key_e * bp.dvs[2]) * 2     // dK / dV are [B, H / kvg, Sk, D]
+                             : bp.dk + (b * bp.dks[0] + hk * bp.dks[1] + (int64_t)key_e * bp.dks[2]) * 2;
         const float sc = role == 0 ? (DROP ? p.drop_scale : 1.0f) : bp.scale;
 #pragma unroll
-        for (int d = 0; d < DB; ++d) store_block_narrow<E>(rp + d * 64, acc[d], sc, hi);   // (8-byte stores: at its register limit, fasn_common.h)
+        for (int d = 0; d < DB; ++d) store_block_narrow<E>(rp + d * 64, acc[d], sc, hi_e);   // (8-byte stores: at its register limit, fasn_common.h)
     }
 }
 

@@ -237,8 +237,9 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
                 const int g = r >> 2;
                 const uint32_t own = drop_mix(drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)(r0 + 8 * g + 4 * hi + (lane & 3))), dsd.hi, (uint32_t)(key >> 4));   // (one per g: CSE)
                 const bool keep = (int32_t)drop_word(quad_bcast(own, r & 3), dlane) >= dthr.hi32;   // the state of THIS register's row, from the lane of the key quad that computed it
-                s[r] = keep ? pv : 0.f;                                             // what dV multiplies (its 1/(1-p) at the end)
-                pp[r] = pv * ((keep ? pp[r] * p.drop_scale : 0.f) + xr[r]);          // dS = P o (dropped dP - delta)
+                const float ks = keep ? p.drop_scale : 0.f;                          // ONE select per weight: the factor 1 / (1 - p) or 0
+                s[r] = pv * ks;                                                     // what dV multiplies
+                pp[r] = pv * __builtin_fmaf(pp[r], ks, xr[r]);                       // dS = P o (dropped dP - delta)
             } else {
                 s[r] = pv;
                 pp[r] = pv * pp[r];
@@ -356,7 +357,7 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dkdv_pipe_kernel(const BwdPar
 #pragma unroll
         for (int d = 0; d < DB; ++d) {   // 16-byte stores (round 5, store_block_wide in fasn_common.h)
             store_block_wide<E>(rk + d * 64, dkacc[d], bp.scale, hi);
-            store_block_wide<E>(rv + d * 64, dvacc[d], DROP ? p.drop_scale : 1.0f, hi);
+            store_block_wide<E>(rv + d * 64, dvacc[d], 1.0f, hi);   // (dropout: the kept weights entered already scaled by 1 / (1 - p))
         }
     }
     }   // pass
