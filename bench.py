@@ -477,15 +477,33 @@ def main():
             ref = ref_attention_n(qc, kc, vc, softmax_n_param=n, is_causal=causal, attn_bias=bc, attn_mask=mc)
         cpu_dt = (time.perf_counter() - t1) / reps
         frac = (nb * hs) / (B * H)
+        # the sample predicts the whole workload: when that is within the budget of a bounded baseline (<= 25 s), run ALL of it - the remaining
+        # (batch, head) slices through the same call - and report the measured time of one whole forward op instead of an extrapolation
+        whole = False
+        if not full and mask is None and cpu_dt / frac <= 25.0:
+            qh, kh, vh = q.cpu(), k.cpu(), v.cpu()   # (outside the timed region: the baseline's inputs are resident in host memory, as the GPU's are in HBM)
+            bh_ = None if bias is None else bias.cpu()
+            t1 = time.perf_counter()
+            for b0 in range(B):
+                for h0 in range(0, H, hs):
+                    if b0 == 0 and h0 == 0:
+                        continue
+                    ref_attention_n(qh[b0:b0 + 1, h0:h0 + hs], kh[b0:b0 + 1, h0:h0 + hs], vh[b0:b0 + 1, h0:h0 + hs], softmax_n_param=n,
+                                    is_causal=causal, attn_bias=None if bh_ is None else bh_[h0:h0 + hs])
+            cpu_dt += time.perf_counter() - t1
+            frac, whole = 1.0, True
+            del qh, kh, vh
         cpu_model = platform.processor() or "unknown"
         try:
             cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         except Exception:
             pass
-        line["cpu_baseline"] = {"value": frac / cpu_dt, "unit": "attn-ops/s (forward)", "cores": threads, "kind": "port", "extrapolated": not full,
+        line["cpu_baseline"] = {"value": frac / cpu_dt, "unit": "attn-ops/s (forward)", "cores": threads, "kind": "port", "extrapolated": not (full or whole),
                                 "cpu": cpu_model,
                                 "sample": (f"IN FULL: the whole (B={B},H={H},S={S},D={D}) {dname} forward, mean of {reps} runs = {cpu_dt * 1e3:.3f} ms; "
                                            f"oracle/ref_attention.py (eager, as slow_attention_n)") if full else
+                                          (f"IN FULL: every (batch, head) slice of the (B={B},H={H},S={S},D={D}) {dname} forward, {hs} heads per call, {cpu_dt:.2f} s in all "
+                                           f"(inputs resident in host memory); oracle/ref_attention.py (eager {dname}, as slow_attention_n)") if whole else
                                           (f"EXTRAPOLATED: batch 0, heads 0..{hs - 1} of the same inputs ({hs}/{B * H} of one forward op) took {cpu_dt:.2f} s, "
                                            f"scaled linearly x{B * H // hs}; oracle/ref_attention.py (eager {dname}, as slow_attention_n)")}
         out = out_holder.get("o")
