@@ -385,8 +385,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
                     const uint32_t word = pw[t2][e >> 1];
                     const float pv = E::to_f32((uint16_t)((e & 1) ? (word >> 16) : (word & 0xffffu)));
                     if (DROP) {   // sign set = dropped weight: dS = |P| ((kept ? dP / (1-p) : 0) - delta)   (stat = -delta)
-                        const float dpe = __builtin_signbit(pv) ? 0.f : pacc[8 * t2 + e] * p.drop_scale;
-                        x[e] = __builtin_fabsf(pv) * (dpe + stat);
+                        const float ks = __builtin_signbit(pv) ? 0.f : p.drop_scale;   // (one select: the factor)
+                        x[e] = __builtin_fabsf(pv) * __builtin_fmaf(pacc[8 * t2 + e], ks, stat);
                     } else {
                         x[e] = pv * pacc[8 * t2 + e];
                     }

@@ -939,10 +939,10 @@ __global__ void __launch_bounds__(256, 2) fasn_bwd_dq_pipe_kernel(const BwdParam
             f32x8 y;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (DROP) {
+                if (DROP) {   // sign set = dropped weight: dS = |P| (dP * (kept ? 1 / (1 - p) : 0) - delta) - one select (the factor), one fma, one multiply
                     const float pv = s[8 * t2 + e];
-                    const float dpe = __builtin_signbit(pv) ? 0.f : pa[8 * t2 + e] * p.drop_scale;
-                    y[e] = __builtin_fabsf(pv) * (dpe + ndlt);
+                    const float ks = __builtin_signbit(pv) ? 0.f : p.drop_scale;
+                    y[e] = __builtin_fabsf(pv) * __builtin_fmaf(pa[8 * t2 + e], ks, ndlt);
                 } else {
                     y[e] = s[8 * t2 + e] * pa[8 * t2 + e];
                 }

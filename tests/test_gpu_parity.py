@@ -931,6 +931,52 @@ def test_dropout_matches_oracle_with_explicit_mask(pkg, dev, D, mode, dtype):
     assert not torch.equal(out, pkg.flash_attention_n(q, k, v, dropout_p=p, attn_mask=mask, attn_bias=bias, **kw))
 
 
+def _plan_args(pkg, q, k, v, dropout_p=0.0, softmax_n_param=1.0, is_causal=False, attn_mask=None):
+    """a BwdArgs block for fasn_launch_plan (nothing is launched: output / gradient pointers only have to be aligned device addresses)"""
+    a = pkg._lib.BwdArgs()
+    B, H, L, D = q.shape
+    m8 = None if attn_mask is None else attn_mask.expand(B, H, L, k.shape[2]).view(torch.uint8)
+    pkg.flash_attn._fill_fwd(a.fwd, q.detach(), k.detach(), v.detach(), q.detach(), torch.empty(B, H, L, device=q.device), m8, None,
+                             softmax_n_param, D ** -0.5, is_causal, dropout_p)
+    a.dout, a.dq, a.dk, a.dv = (pkg.flash_attn._view4(t.detach()) for t in (q, q, k, k))
+    a.delta = a.fwd.lse
+    return a
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["plain", "causal", "keypad"])
+def test_dropout_at_the_plain_kernels_tuning_points(pkg, dev, mode, dtype):
+    """Round 6 (dropout stream definition 2): the keep bits are applied to the PACKED weights behind the row sums, so the dropout forward runs at
+    the plain kernels' tuning points - 64 rows per wave with packed row sums for grids of a full round (here (8,16,1024,64): 512 blocks of 256
+    rows), three waves per SIMD below - and the backward on the pipelined kernels. Exact parity with the oracle under the explicit mask of the
+    host mirror on a spread of (batch, head) slices, forward and gradients; every element of the full outputs finite; the dropped fraction is
+    the requested one."""
+    B, H, L, D, p = 8, 16, 1024, 64, 0.15
+    q, k, v = (_rand((B, H, L, D), dtype, dev, s).requires_grad_() for s in (61, 62, 63))
+    do = _rand((B, H, L, D), dtype, dev, 64, std=1.0)
+    kw = dict(softmax_n_param=1.0)
+    if mode == "causal":
+        kw["is_causal"] = True
+    if mode == "keypad":
+        kw["attn_mask"] = synth.keypad_mask(B, L, device=dev)
+    names = [n for n, *_ in pkg._lib.launch_plan_described(_plan_args(pkg, q, k, v, dropout_p=p, **kw), pkg._lib.FASN_PLAN_FWD)]
+    assert len(names) == 1 and "DROP=1" in names[0] and "SEED=2" in names[0] and ("QB=2" in names[0]) == (mode != "causal"), names
+    torch.manual_seed(123)
+    out = pkg.flash_attention_n(q, k, v, dropout_p=p, **kw)
+    out.backward(do)
+    for t in (out, q.grad, k.grad, v.grad):
+        assert torch.isfinite(t).all()
+    seed, offset = pkg.flash_attn.last_dropout_state()
+    keep = pkg.dropout.keep_mask(seed, offset, B, H, L, L, p)
+    assert abs((1.0 - keep.mean()) - pkg.dropout.effective_p(p)) < 1e-3
+    for b, h in ((0, 0), (3, 9), (7, 15)):
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        okw = {a: (c[b:b + 1].cpu() if a == "attn_mask" else c) for a, c in kw.items()}
+        o, dq, dk, dv = _oracle_dropout(q[sl], k[sl], v[sl], do[sl], keep[b:b + 1, h:h + 1], pkg.dropout.effective_p(p), **okw)
+        for got, want, nm in ((out[sl], o, "out"), (q.grad[sl], dq, "dq"), (k.grad[sl], dk, "dk"), (v.grad[sl], dv, "dv")):
+            _check(got, want, dtype, f"dropout {mode} [{b},{h}] {nm}")
+
+
 def test_dropout_reference_grid_is_finite_and_unbiased(pkg, dev):
     """the reference's own dropout check (tests/gpu/core/test_flash_attn.py:26-27,41-44) only asks for finite sums; also
     check E[dropout(w)] = w: averaging over seeds approaches the no-dropout output"""
