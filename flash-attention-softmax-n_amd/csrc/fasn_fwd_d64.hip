@@ -27,6 +27,25 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
             default: break;
         }
     }
+    // Round 6: the vector mask / bias modes of a large grid run EIGHT waves x 64 rows per workgroup, direct-to-LDS, one workgroup per CU (two
+    // waves per SIMD, every K / V fragment read from LDS feeds two row blocks; 213 - 256 registers, no spill) - same box, (4,16,4096,64) ALiBi +
+    // key padding forward: 0.443 -> 0.388 ms (-12 %; four waves x 32 rows direct-to-LDS: 0.412 / 0.425 with two / three waves per SIMD;
+    // profiles/r06_d64_bias_forward_tuning_points_ab.log). Small grids keep four waves x 32 rows, register-staged.
+#ifndef FASN_D64_BIAS_8WAVE
+#define FASN_D64_BIAS_8WAVE 1
+#endif
+    const long blocks512 = (long)((p.Sq + 511) / 512) * p.B * p.H;
+    // (a full round of one workgroup per CU; the bias + key-padding mode pairs its batch elements by length - half as many workgroups - and needs
+    // two: at (8,16,1024,64), 256 blocks, the paired 8-wave launch left half of the CUs idle, 0.089 against 0.064 ms)
+    if (FASN_D64_BIAS_8WAVE && blocks512 >= (l.mode == MODE_BIAS_KEYPAD ? 512 : 256) && p.Sq >= 512) {
+        switch (l.mode) {
+            case MODE_GENERAL: return launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 2, 8, 2, 2>(p, s);
+            case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 2, MODE_GENERAL_B, 2, 8, 2, 2>(p, s);
+            case MODE_GENERAL_M: return launch_fwd_one<Tag, 64, 2, MODE_GENERAL_M, 2, 8, 2, 2>(p, s);
+            case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 64, 2, MODE_BIAS_KEYPAD, 2, 8, 2, 2>(p, s);
+            default: break;
+        }
+    }
     switch (l.mode) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL, 2, 4, 0, 2>(p, s);
         case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 1, MODE_GENERAL_B, 2, 4, 0, 2>(p, s);

@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // (thread c: 16 bytes -> 16 bits; a tile then costs one uniform ds_read_b64 instead of a global load per wave and tile, whose
     // compiler-counted wait also drained the K/V prefetch). Trailing tiles without a visible key are not walked at all.
     constexpr int IMGB = BF32 ? 8192 : 4096;                          // bias image of one 32-row block and tile: [32 rows][64 keys] 16 bit / fp32
-    constexpr int IMGM = (BF32 && !mode_has_vmask(MODE)) ? 0 : 2048;   // mask image [32 rows][64 bytes] (the fp32 instantiations without a mask operand do not reserve it)
+    constexpr int IMGM = mode_has_vmask(MODE) ? 2048 : 0;              // mask image [32 rows][64 bytes] (only the instantiations with a dense-mask operand reserve it)
     constexpr int BPC = BF32 ? 16 : 8;                                 // 16-byte chunks per bias image row
     constexpr int BW = BF32 ? 16 : 8;                                  // dwords a lane holds per 32-key block (16 keys)
     uint64_t* const ldsKP = reinterpret_cast<uint64_t*>(smem + 2 * (RING == 2 ? 3 : 2) * (KT * D * 2) + (mode_is_vector(MODE) ? NW * QB * (IMGB + IMGM) : 0));   // [kFwdKpMaxTiles]

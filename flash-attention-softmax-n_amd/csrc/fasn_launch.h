@@ -61,8 +61,8 @@ inline int launch_rc() { return (t_launch_log != nullptr || hipGetLastError() ==
 
 constexpr bool mode_is_vec(int MODE) { return mode_is_vector(MODE); }
 constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB, int BF32 = 0) {
-    // K/V buffers + per-wave bias / mask images (fp32 bias: 8 KiB instead of 4, and no mask area unless the mode has a mask operand) + key-padding visibility words
-    return (RING == 2 ? 6 : 4) * KT * D * 2 + (mode_is_vec(MODE) ? NW * QB * ((BF32 ? 8192 : 4096) + ((BF32 && !mode_has_vmask(MODE)) ? 0 : 2048)) : 0) +
+    // K/V buffers + per-wave bias / mask images (fp32 bias: 8 KiB instead of 4; the mask area only in the modes with a dense-mask operand) + key-padding visibility words
+    return (RING == 2 ? 6 : 4) * KT * D * 2 + (mode_is_vec(MODE) ? NW * QB * ((BF32 ? 8192 : 4096) + (mode_has_vmask(MODE) ? 2048 : 0)) : 0) +
            (mode_has_keypad(MODE) ? kFwdKpMaxTiles * 8 : 0);
 }
 
