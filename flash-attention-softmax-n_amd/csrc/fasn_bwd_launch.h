@@ -152,17 +152,21 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
             return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), 1, 0, 0, 1, 1>(p, s);   // bias alone or bias + dense mask
         }
     }
+    // Vector mask / bias modes on the one-wave kernels: two waves per SIMD at head dims 32 and 64. Head dim 32 (round 6): ONE 32-row / 32-key block
+    // per wave - with two the kernels needed 272 / 344 registers and were compiled for one wave per SIMD; with one they need 144 / 161
+    // (profiles/r06_d32_vector_modes_two_waves_per_simd_ab.log).
+    constexpr int VQB = D == 32 ? 1 : QB, VKB = D == 32 ? 1 : KB, VOCC = D <= 64 ? 2 : 1;
     switch (mode) {
         case MODE_PLAIN: return launch_bwd_one<Tag, D, QB, KB, MODE_PLAIN, OCC_Q, OCC_K, 0, WS>(p, s);
         case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KB, MODE_CAUSAL, OCC_Q, OCC_K, 0, WS>(p, s);
         case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_KEYPAD, OCC_Q, OCC_K, 0, WS>(p, s);   // key-padding mask: plain kernels + visibility bits
         case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1>(p, s);
         // vector bias + visibility bits (dQ at D = 128 with two waves per SIMD spills and its 88 KiB of LDS admit one workgroup per CU anyway: 12.7 vs 8.4 ms)
-        case MODE_BIAS_KEYPAD: return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 0, WS>(p, s);
+        case MODE_BIAS_KEYPAD: return launch_bwd_one<Tag, D, VQB, VKB, MODE_BIAS_KEYPAD, VOCC, VOCC, 0, WS>(p, s);
         case MODE_GENERAL_B:   // bias only: with the two-wave dK/dV kernel the same instantiation without a mask (every key kept)
-            if constexpr (WS != 0) return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 0, WS>(p, s);
-            else return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1)>(p, s);
-        default: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 0, WS>(p, s);   // vector path (bias and/or mask)
+            if constexpr (WS != 0) return launch_bwd_one<Tag, D, VQB, VKB, MODE_BIAS_KEYPAD, VOCC, VOCC, 0, WS>(p, s);
+            else return launch_bwd_one<Tag, D, VQB, VKB, MODE_GENERAL, VOCC, VOCC>(p, s);
+        default: return launch_bwd_one<Tag, D, VQB, VKB, MODE_GENERAL, VOCC, VOCC, 0, WS>(p, s);   // vector path (bias and/or mask)
     }
 }
 

@@ -11,11 +11,19 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
             default: break;
         }
     }
+    // (round 6: compiled for TWO waves per SIMD, direct-to-LDS - 178 - 207 registers, no spill; round 5 compiled them for one wave per SIMD,
+    // 324 registers; profiles/r06_d32_vector_modes_two_waves_per_simd_ab.log)
+#ifndef FASN_D32_VEC_OCC
+#define FASN_D32_VEC_OCC 2
+#endif
+#ifndef FASN_D32_VEC_RING
+#define FASN_D32_VEC_RING 2
+#endif
     switch (l.mode) {
-        case MODE_GENERAL: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, 1, 4, 0, 2>(p, s);
-        case MODE_GENERAL_B: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_B, 1, 4, 0, 2>(p, s);
-        case MODE_GENERAL_M: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_M, 1, 4, 0, 2>(p, s);
-        case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 32, 2, MODE_BIAS_KEYPAD, 1, 4, 0, 2>(p, s);
+        case MODE_GENERAL: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, FASN_D32_VEC_OCC, 4, FASN_D32_VEC_RING, 2>(p, s);
+        case MODE_GENERAL_B: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_B, FASN_D32_VEC_OCC, 4, FASN_D32_VEC_RING, 2>(p, s);
+        case MODE_GENERAL_M: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_M, FASN_D32_VEC_OCC, 4, FASN_D32_VEC_RING, 2>(p, s);
+        case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 32, 2, MODE_BIAS_KEYPAD, FASN_D32_VEC_OCC, 4, FASN_D32_VEC_RING, 2>(p, s);
         default: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_SLOW, 1>(p, s);
     }
 }

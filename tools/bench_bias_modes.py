@@ -1,12 +1,13 @@
 """Forward (and forward + backward) of flash_attention_n in the vector mask / bias modes at head dim 64, large and small grids: ALiBi [H,L,S]
 bias + key padding, bias alone, dense boolean mask, bias + dense mask. Lines carry "ms_per_step" so that tools/ab_libs.sh can alternate
-libraries:  python tools/bench_bias_modes.py [fwd|fwdbwd]"""
+libraries:  python tools/bench_bias_modes.py [fwd|fwdbwd] [head dim]"""
 import sys, torch
 sys.path.insert(0, '/root/repo')
 import flash_attention_softmax_n_amd as pkg
 from flash_attention_softmax_n_amd import synth
 dev = torch.device('cuda:0')
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+DD = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 def timeit(fn, iters, warm=5):
     for _ in range(warm): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -14,7 +15,7 @@ def timeit(fn, iters, warm=5):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-for (B, H, S, D) in ((4, 16, 4096, 64), (8, 16, 1024, 64), (16, 16, 512, 64), (32, 8, 128, 64)):
+for (B, H, S, D) in ((4, 16, 4096, DD), (8, 16, 1024, DD), (16, 16, 512, DD), (32, 8, 128, DD)):
     q, k, v = (synth.counter_normal((B, H, S, D), s, dtype=torch.bfloat16, device=dev).requires_grad_(which != "fwd") for s in (101, 102, 103))
     do = synth.counter_normal((B, H, S, D), 104, std=1.0, dtype=torch.bfloat16, device=dev)
     bias = synth.alibi_bias(H, S, S, torch.bfloat16, device=dev)
