@@ -172,7 +172,7 @@ struct TileDma {
 template <typename Tag, int D, int QB, int MODE, int OCC, int DROP = 0, int DQ_SEED = (D >= 128 ? FASN_DQ_SEED_D128 : D == 32 ? FASN_DQ_SEED_D32 : 3), int BF32 = 0>
 __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams bp) {
     static_assert(!BF32 || mode_has_vbias(MODE), "fp32 bias image: the vector bias modes");
-    constexpr int IMGB = BF32 ? 8192 : 4096, IMGM = (BF32 && !mode_has_vmask(MODE)) ? 0 : 2048, BPC = BF32 ? 16 : 8, BW = BF32 ? 16 : 8;   // (fasn_fwd_kernel.h)
+    constexpr int IMGB = BF32 ? 8192 : 4096, IMGM = mode_has_vmask(MODE) ? 2048 : 0, BPC = BF32 ? 16 : 8, BW = BF32 ? 16 : 8;   // (fasn_fwd_kernel.h)
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     const FwdParams& p = bp.f;

@@ -67,7 +67,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     if constexpr (ONE_WAVE) {
     if (!dq_done) {   // dQ
         constexpr int BM = 4 * QB * 32;
-        constexpr int smem = 4 * KT * D * 2 + (mode_is_vector(MODE) ? 4 * QB * ((BF32 ? 8192 : 4096) + ((BF32 && !mode_has_vmask(MODE)) ? 0 : 2048)) : 0);   // + per-wave bias / mask images
+        constexpr int smem = 4 * KT * D * 2 + (mode_is_vector(MODE) ? 4 * QB * ((BF32 ? 8192 : 4096) + (mode_has_vmask(MODE) ? 2048 : 0)) : 0);   // + per-wave bias / mask images (the mask area only with a dense-mask operand)
         p.nblk = (p.f.Sq + BM - 1) / BM;
         constexpr auto kern = &fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q, DROP, (D >= 128 ? FASN_DQ_SEED_D128 : D == 32 ? FASN_DQ_SEED_D32 : 3), BF32>;
         ensure_smem<kern>(smem);
@@ -140,7 +140,7 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
             case MODE_CAUSAL: return launch_bwd_one<Tag, D, QB, KBD, MODE_CAUSAL, OCC_Q, OCC_K, 1, WS>(p, s);
             case MODE_KEYPAD: return launch_bwd_one<Tag, D, QB, KBD, MODE_KEYPAD, OCC_Q, OCC_K, 1, WS>(p, s);
             case MODE_GENERAL_SLOW: return launch_bwd_one<Tag, D, QB, KB, MODE_GENERAL_SLOW, 1, 1, 1>(p, s);
-            default: return launch_bwd_one<Tag, D, QB, KBD, MODE_GENERAL, (D == 64 ? 2 : 1), (D == 64 ? 2 : 1), 1>(p, s);   // vector mask / bias
+            default: return launch_bwd_one<Tag, D, (D == 32 ? 1 : QB), KBD, MODE_GENERAL, (D <= 64 ? 2 : 1), (D <= 64 ? 2 : 1), 1>(p, s);   // vector mask / bias (head dim 32: one block per wave, two waves per SIMD, as without dropout)
         }
     }
     if constexpr (D <= 128) {   // fp32 bias next to 16-bit q / k / v on the vector path (fasn_api.hip: f32_bias_vector); D = 128: the ONE-wave kernels (the two-wave ones have no LDS left for 8 KiB images)

@@ -153,7 +153,7 @@ int launch_fwd_drop(const FwdParams& p, int mode, hipStream_t s) {
     }
     if (mode == MODE_GENERAL || mode == MODE_GENERAL_B || mode == MODE_GENERAL_M) {
         if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_GENERAL, 2, 8, 2, 2, 1>(p, s);
-        else return launch_fwd_one<Tag, D, (D == 32 ? 2 : 1), MODE_GENERAL, (D == 32 ? 1 : 2), 4, 0, 2, 1>(p, s);   // (the p = 0 vector kernels' tuning points)
+        else return launch_fwd_one<Tag, D, (D == 32 ? 2 : 1), MODE_GENERAL, 2, 4, (D == 32 ? 2 : 0), 2, 1>(p, s);   // (the p = 0 vector kernels' small-grid tuning points)
     }
     return launch_fwd_one<Tag, D, (D == 32 ? 2 : 1), MODE_GENERAL_SLOW, 1, 4, 0, 0, 1>(p, s);
 }
