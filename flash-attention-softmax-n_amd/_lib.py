@@ -20,7 +20,7 @@ FASN_PLAN_FWD, FASN_PLAN_BWD, FASN_PLAN_FWD_WS = 0, 1, 2
 
 # every entry point include/fasn.h declares (tests check the .so exports all of them)
 EXPORTS = (
-    "fasn_abi_version", "fasn_strerror", "fasn_supported", "fasn_fwd", "fasn_fwd_path", "fasn_fwd_workspace_bytes", "fasn_fwd_ws",
+    "fasn_abi_version", "fasn_strerror", "fasn_supported", "fasn_fwd", "fasn_fwd_path", "fasn_bwd_path", "fasn_fwd_workspace_bytes", "fasn_fwd_ws",
     "fasn_bwd_workspace_bytes", "fasn_bwd", "fasn_rng_advance", "fasn_launch_plan",
     "fasn_softmax_n_fwd", "fasn_softmax_n_bwd", "fasn_moments",
 )
@@ -84,6 +84,8 @@ def load():
     lib.fasn_fwd.argtypes = [POINTER(FwdArgs), c_void_p]
     lib.fasn_fwd_path.restype = c_int32
     lib.fasn_fwd_path.argtypes = [POINTER(FwdArgs)]
+    lib.fasn_bwd_path.restype = c_int32
+    lib.fasn_bwd_path.argtypes = [POINTER(BwdArgs)]
     lib.fasn_fwd_workspace_bytes.restype = c_size_t
     lib.fasn_fwd_workspace_bytes.argtypes = [POINTER(FwdArgs)]
     lib.fasn_fwd_ws.restype = c_int32

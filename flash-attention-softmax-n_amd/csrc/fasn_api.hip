@@ -385,7 +385,10 @@ int fasn_fwd_path(const fasn_fwd_args* args) {
     if (l.dtype == FASN_DTYPE_F32) return FASN_PATH_FP32;
     int mode = l.mode;
     if (p.drop_thr && mode == MODE_BIAS_KEYPAD) mode = p.keypad_fallback;   // (no dropout instantiation of its own)
-    if (p.drop_thr && l.D > 128) return FASN_PATH_ELEMENT;                  // D = 256: dropout on the element-load kernels
+    if (l.D > 128 && (p.drop_thr || mode == MODE_BIAS_KEYPAD)) {            // D = 256: dropout and bias + key padding through the general modes (launch_fwd_d256)
+        if (mode == MODE_KEYPAD || mode == MODE_BIAS_KEYPAD) mode = p.keypad_fallback;
+        if (p.drop_thr) return mode == MODE_GENERAL_SLOW ? FASN_PATH_ELEMENT : FASN_PATH_VECTOR;
+    }
     switch (mode) {
         case MODE_PLAIN: case MODE_CAUSAL: return FASN_PATH_PLAIN;
         case MODE_KEYPAD: return FASN_PATH_KEYPAD;
@@ -570,6 +573,20 @@ int fasn_launch_plan(const fasn_bwd_args* args, int32_t which, char* buf, size_t
     t_launch_log = outer;
     if (rc) return rc;
     return log.len > cap ? FASN_EINVAL : (int)log.len;
+}
+
+
+// The family the BACKWARD of a call is routed to: asked of the launch tables themselves (a recorded plan whose dQ / dK/dV kernels are
+// element-load instantiations), so it cannot drift from them. Differs from fasn_fwd_path at head dim 256, where masks other than key padding
+// and every bias have vector kernels in the forward only.
+int fasn_bwd_path(const fasn_bwd_args* args) {
+    if (args == nullptr) return FASN_EINVAL;
+    const int fp = fasn_fwd_path(&args->fwd);
+    if (fp < 0 || fp == FASN_PATH_FP32 || fp == FASN_PATH_ELEMENT) return fp;
+    char buf[2048];
+    const int n = fasn_launch_plan(args, FASN_PLAN_BWD, buf, sizeof buf);
+    if (n < 0) return n;
+    return strstr(buf, "element-load") != nullptr ? FASN_PATH_ELEMENT : fp;
 }
 
 }  // extern "C"

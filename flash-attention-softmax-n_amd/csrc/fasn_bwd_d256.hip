@@ -1,7 +1,8 @@
 // D = 256 backward instantiations: the one-wave dQ and dK/dV kernels with the whole register file (one wave per SIMD:
 // dQ^T is 128 accumulator registers next to 128 of Q / dO fragments; dK^T + dV^T would be 256 next to 128 of K / V fragments, so
 // the dK/dV kernel runs as two workgroups per key block that each own half of the features, DH = 2).
-// Key padding: the two-wave kernels too (kvg == 1), else the plain one-wave kernels; dense masks, bias and dropout take the element-load kernels.
+// Key padding: the two-wave kernels too (kvg == 1), else the plain one-wave kernels; dense masks, 16-bit bias and dropout take the one-wave vector
+// kernels (round 6), operands whose rows do not move as vectors the element-load kernels.
 #include "fasn_bwd_launch.h"
 #include "fasn_bwd_ws256.h"
 namespace fasn {
@@ -54,7 +55,11 @@ static int launch_ws256(BwdParams p, hipStream_t s) {
 template <typename Tag>
 static int go(const BwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_BIAS_KEYPAD) mode = p.f.keypad_fallback;   // bias + key padding: the dense-mask view of the same mask
-    if (p.f.drop_thr) return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL_SLOW, 1, 1, 1, 0, 2>(p, s);
+    if (p.f.drop_thr) {   // dropout (round 6): ONE vector instantiation for every mode whose mask / bias rows move as vectors - no operand at all included
+        const int md = mode == MODE_KEYPAD ? p.f.keypad_fallback : mode;
+        if (md == MODE_GENERAL_SLOW) return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL_SLOW, 1, 1, 1, 0, 2>(p, s);
+        return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 1, 0, 2>(p, s);
+    }
     if (!(FASN_BWD_VARIANT & 1)) {   // (developer library: bwd_variant bit 0 = the round-3 feature-half kernels, for A/B)
         if (mode == MODE_PLAIN) return launch_ws256<Tag, MODE_PLAIN>(p, s);      // (grouped K/V included since round 5)
         if (mode == MODE_CAUSAL) return launch_ws256<Tag, MODE_CAUSAL>(p, s);
@@ -66,8 +71,9 @@ static int go(const BwdParams& p, int mode, hipStream_t s) {
 #endif
         case MODE_PLAIN:   // the key-padding instantiation without a mask (every key visible): the plain one spills at this head dim
         case MODE_KEYPAD: return launch_bwd_one<Tag, 256, 1, 1, MODE_KEYPAD, 1, 1, 0, 0, 2>(p, s);
-        // dense masks / bias: the element-load kernels (the dK/dV kernel's additive tile next to four 32 KiB Q / dO buffers would
-        // need 161 KiB of LDS)
+        // dense masks / 16-bit bias with vector-movable rows (round 6): the one-wave vector kernels - the dK/dV kernel with ONE additive tile
+        // (two of them next to four 32 KiB Q / dO buffers would need 161 KiB of LDS; round 5 sent these calls to the element-load kernels, 3 x slower)
+        case MODE_GENERAL: case MODE_GENERAL_B: case MODE_GENERAL_M: return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 0, 0, 2>(p, s);
         default: return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL_SLOW, 1, 1, 0, 0, 2>(p, s);
     }
 }

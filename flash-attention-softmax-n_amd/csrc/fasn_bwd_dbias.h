@@ -336,10 +336,11 @@ __global__ void __launch_bounds__(256, 1) fasn_bwd_dbias_kernel(const DbiasParam
                     sacc[r] = bseed[tt][kb][r] + nlse2;
                     pacc[r] = ndlt;
                 }
+                const int lane_k = D == 256 ? fresh_lane_id() : lane;   // (D = 256: the 32 fragment addresses recomputed per block instead of parked in scratch)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + l31, ks, hi);
-                    const vec8 vf = lds_read_rowfrag<E, D>(tV, kb * 32 + l31, ks, hi);
+                    const vec8 kf = lds_read_rowfrag<E, D>(tK, kb * 32 + (lane_k & 31), ks, lane_k >> 5);
+                    const vec8 vf = lds_read_rowfrag<E, D>(tV, kb * 32 + (lane_k & 31), ks, lane_k >> 5);
                     sacc = E::mfma(kf, qf[ks], sacc);
                     pacc = E::mfma(vf, dof[ks], pacc);
                 }

@@ -26,6 +26,9 @@
 namespace fasn {
 
 #ifndef FASN_EXP_BIASHOT
+#ifndef FASN_WS_FRESH_DV
+#define FASN_WS_FRESH_DV 1
+#endif
 #define FASN_EXP_BIASHOT 0   // experiment: every bias request reads the first rows (always an L2 hit): separates fetch latency from issue cost
 #endif
 #ifndef FASN_WS_ATTR
@@ -426,6 +429,11 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
             *LDS_PTR(u32x4, ps + 1024) = w1;
         };
         auto dv_gemm = [&](int qb, const vec8 (&pfr)[2]) {   // dV^T[d][key] += dO^T[d][q] P[q][key]
+            // The addresses of the transposed dO reads from a fresh lane id (round 6) in the instantiations that otherwise keep 1 - 14 of them in scratch
+            // across the tile loop (dropout, grouped K/V, fp16 bias + key padding); the others have the registers, and recomputing the addresses per
+            // block costs them 2 % (config 4 backward 13.68 -> 13.97 ms)
+            constexpr bool FRESH = FASN_WS_FRESH_DV && (DROP || GQA || (MODE == MODE_BIAS_KEYPAD && std::is_same<Tag, f16_tag>::value));
+            const int lane = FRESH ? fresh_lane_id() : (int)(threadIdx.x & 63);
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll

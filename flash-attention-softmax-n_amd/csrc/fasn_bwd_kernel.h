@@ -20,6 +20,9 @@
 #include "fasn_common.h"
 #include "fasn_fwd_kernel.h"
 
+#ifndef FASN_DKDV256_FRESH
+#define FASN_DKDV256_FRESH 1
+#endif
 namespace fasn {
 
 struct BwdParams {
@@ -580,13 +583,15 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
                 }
             }
             // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+            // (D = 256 element-load mode: the addresses of the transposed reads from a fresh lane id, see the dK/dV kernel)
+            const int lane_t = (D == 256 && MODE == MODE_GENERAL_SLOW && FASN_DKDV256_FRESH) ? fresh_lane_id() : lane;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                     for (int d = 0; d < DB; ++d) {
-                        vec8 ktf = lds_read_trfrag<E, D>(tK, kb * 32 + 16 * t2, d, lane);
+                        vec8 ktf = lds_read_trfrag<E, D>(tK, kb * 32 + 16 * t2, d, lane_t);
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) dqacc[qb][d] = E::mfma(ktf, dsf[qb][kb][t2], dqacc[qb][d]);
                     }
@@ -763,7 +768,8 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     float stL = 0.f, stX = 0.f;
     auto stats_gload = [&](int row0) {
         if (tid < QT) {
-            const int gr = row0 + tid;
+            // (grouped K/V at D = 256 or with dropout: the row offset from a fresh lane id - kept across the head loop it was the one value that went to scratch)
+            const int gr = row0 + ((GQA && (D == 256 || DROP)) ? wave * 64 + fresh_lane_id() : tid);
             float l = 0.f, x = 0.f;
             if (gr < p.Sq) {
                 l = lsebase[gr];
@@ -810,7 +816,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     constexpr int KPC = BF32 ? 4 : 8;               // keys per 16-byte chunk of the bias
     constexpr int ADDB = QT * BN_ * (BF32 ? 4 : 2); // bytes of one additive tile = BN_/128 swizzled [64][128] 16-bit images, or [64][BN_] fp32 row major
     constexpr int ACH = (QT * BN_ / KPC) / 256;     // chunks per thread
-    char* const ldsAdd = smem + 4 * TILEB + 4 * QT * 4;   // [2][ADDB]
+    char* const ldsAdd = smem + 4 * TILEB + 4 * QT * 4;   // [ADD_BUFS][ADDB]
+    // D = 256: ONE additive tile (four 32 KiB Q / dO buffers + two 16 KiB tiles would be 161 KiB); the next tile then waits in its staging
+    // registers for a barrier of its own behind the q tile's last read. Elsewhere two, filled ahead of the barrier that ends the q tile.
+    constexpr int ADD_BUFS = D == 256 ? 1 : 2;
     __amdgpu_buffer_rsrc_t brs, mrs;
     unsigned abvo0 = 0, amvo0 = 0;   // chunk 0 of this thread; chunk i is RSTEP rows further down (wave-uniform offset)
     constexpr int RSTEP = 256 / (BN_ / KPC);
@@ -845,7 +854,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
             if constexpr (BF32) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) o[w] = (((stM[i][0] | nomask) >> (8 * w)) & 0xffu) ? stA[i][w] : 0xFF800000u;   // -inf where the key's mask byte is clear
-                *LDS_PTR(u32x4, ldsAdd + buf * ADDB + (arow0 + i * RSTEP) * (BN_ * 4) + akc * 16) = o;
+                *LDS_PTR(u32x4, ldsAdd + (ADD_BUFS == 2 ? buf : 0) * ADDB + (arow0 + i * RSTEP) * (BN_ * 4) + akc * 16) = o;
                 continue;
             }
 #pragma unroll
@@ -855,7 +864,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 const uint32_t hi16 = (mw & 0xff00u) ? (stA[i][w] >> 16) : ninf16;
                 o[w] = lo | (hi16 << 16);
             }
-            *LDS_PTR(u32x4, ldsAdd + buf * ADDB + (akc >> 4) * (QT * 256) + tile_off<128>(arow0 + i * RSTEP, akc & 15)) = o;
+            *LDS_PTR(u32x4, ldsAdd + (ADD_BUFS == 2 ? buf : 0) * ADDB + (akc >> 4) * (QT * 256) + tile_off<128>(arow0 + i * RSTEP, akc & 15)) = o;
         }
     };
     if (VEC && tq0 < ntq) {
@@ -913,7 +922,7 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
         }
         const char* tQ = ldsQ + buf * TILEB;
         const char* tD = ldsDO + buf * TILEB;
-        const char* tA = ldsAdd + buf * ADDB;
+        const char* tA = ldsAdd + (ADD_BUFS == 2 ? buf : 0) * ADDB;
         const float* tL = ldsLse + buf * QT;
         const float* tX = ldsDlt + buf * QT;
 
@@ -977,10 +986,11 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
 #pragma unroll
                     for (int r = 0; r < 16; ++r) pacc[kb][r] = SEED_P ? xr[r] : 0.f;
                 }
+                const int lane_s = (D == 256 && MODE == MODE_GENERAL_SLOW && FASN_DKDV256_FRESH) ? fresh_lane_id() : lane;   // (likewise the row fragments' addresses)
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    vec8 qa = lds_read_rowfrag<E, D>(tQ, qb * 32 + l31, s, hi);
-                    vec8 da = lds_read_rowfrag<E, D>(tD, qb * 32 + l31, s, hi);
+                    vec8 qa = lds_read_rowfrag<E, D>(tQ, qb * 32 + (lane_s & 31), s, lane_s >> 5);
+                    vec8 da = lds_read_rowfrag<E, D>(tD, qb * 32 + (lane_s & 31), s, lane_s >> 5);
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) {
                         sacc[kb] = E::mfma(qa, kf[kb][s], sacc[kb]);
@@ -1046,12 +1056,14 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                     }
                 }
                 // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+                // (D = 256 vector modes: the addresses of the transposed reads from a fresh lane id - kept across the tile loop, 43 - 59 of them went to scratch)
+                const int lane_t = (D == 256 && (VEC || MODE == MODE_GENERAL_SLOW) && FASN_DKDV256_FRESH) ? fresh_lane_id() : lane;
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                     for (int d = 0; d < DB; ++d) {
-                        vec8 dot = lds_read_trfrag<E, D>(tD, qb * 32 + 16 * t2, d0 + d, lane);
-                        vec8 qt = lds_read_trfrag<E, D>(tQ, qb * 32 + 16 * t2, d0 + d, lane);
+                        vec8 dot = lds_read_trfrag<E, D>(tD, qb * 32 + 16 * t2, d0 + d, lane_t);
+                        vec8 qt = lds_read_trfrag<E, D>(tQ, qb * 32 + 16 * t2, d0 + d, lane_t);
 #pragma unroll
                         for (int kb = 0; kb < KB; ++kb) {
                             dvacc[kb][d] = E::mfma(dot, pfr[kb][t2], dvacc[kb][d]);
@@ -1066,7 +1078,10 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
                 tsD.lstore(stD, ldsDO + (buf ^ 1) * TILEB);
             }
             stats_lstore(buf ^ 1);
-            if (VEC) add_lstore(buf ^ 1);
+            if (VEC) {
+                if (ADD_BUFS == 1) __syncthreads();   // every wave is done with the tile this one replaces (tq, ntq: the same for the whole workgroup)
+                add_lstore(buf ^ 1);
+            }
         }
         if (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next Q / dO tiles have landed
         __syncthreads();

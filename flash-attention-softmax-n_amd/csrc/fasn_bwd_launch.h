@@ -100,7 +100,8 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     }
     if constexpr (ONE_WAVE) {   // dK, dV
         constexpr int BN = 4 * KB * 32;
-        constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (mode_is_vector(MODE) ? 2 * QT * BN * (BF32 ? 4 : 2) : 0);
+        constexpr int smem = 4 * QT * D * 2 + 4 * QT * 4 + (mode_is_vector(MODE) ? (D == 256 ? 1 : 2) * QT * BN * (BF32 ? 4 : 2) : 0);   // (D = 256: one additive tile, see the kernel)
+        static_assert(smem <= 160 * 1024, "one-wave dK/dV: LDS");
         p.nblk = (p.f.Sk + BN - 1) / BN;
         if (p.f.kvg > 1) {
             constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 1, DH, BF32>;

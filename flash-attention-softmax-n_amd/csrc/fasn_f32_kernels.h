@@ -37,25 +37,24 @@ template <int D>
 struct Stage32 {
     static constexpr int CPR = D / 4;                 // 16-byte chunks per row
     static constexpr int NLD = (64 * CPR) / 256;
-    unsigned voff[NLD];
-    int loff[NLD];
+    static constexpr int RPI = 256 / CPR;             // rows between two pieces of a thread
+    // piece i of a thread is row (tid / CPR) + RPI * i, same chunk: its global offset differs by a wave-uniform amount (added on the scalar
+    // side) and its LDS offset by a constant - except at D = 128 (RPI = 8, the swizzle is row & 15), where odd pieces flip bit 3 of the chunk
+    unsigned voff;
+    int loff[2];
     FASN_DEV void init(int tid, int64_t row_stride) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int ci = tid + i * 256;
-            const int row = ci / CPR, ch = ci % CPR;
-            voff[i] = (unsigned)(row * (int)row_stride * 4 + ch * 16);
-            loff[i] = off32<D>(row, ch);
-        }
+        const int row = tid / CPR, ch = tid % CPR;
+        voff = (unsigned)(row * (int)row_stride * 4 + ch * 16);
+        loff[0] = off32<D>(row, ch);
+        loff[1] = off32<D>(row + RPI, ch) - RPI * D * 4;
     }
     FASN_DEV void gload(u32x4 (&st)[NLD], __amdgpu_buffer_rsrc_t rs, int row0, int64_t row_stride) const {
-        const int soff = row0 * (int)row_stride * 4;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) st[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], soff, 0);
+        for (int i = 0; i < NLD; ++i) st[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (row0 + RPI * i) * (int)row_stride * 4, 0);
     }
     FASN_DEV void lstore(const u32x4 (&st)[NLD], char* tile) const {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) *LDS_PTR(u32x4, tile + loff[i]) = st[i];
+        for (int i = 0; i < NLD; ++i) *LDS_PTR(u32x4, tile + loff[D == 128 ? (i & 1) : 0] + i * (RPI * D * 4)) = st[i];
     }
 };
 
@@ -128,7 +127,7 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
     St sK, sV;
     sK.init(tid, p.ks[2]);
     sV.init(tid, p.vs[2]);
-    u32x4 stK[St::NLD], stV[St::NLD];
+    u32x4 stg[St::NLD];   // one staging set: the next tile's K rows travel during the first S chain, its V rows during the second
     const bool sink = p.n > 0.f;
     float m_run = sink ? 0.f : -INFINITY, l_run = (sink && hi == 0) ? p.n : 0.f;
     f32x16 oacc[DB];
@@ -137,10 +136,10 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     if (ntiles > 0) {
-        sK.gload(stK, krs, 0, p.ks[2]);
-        sV.gload(stV, vrs, 0, p.vs[2]);
-        sK.lstore(stK, ldsK);
-        sV.lstore(stV, ldsV);
+        sK.gload(stg, krs, 0, p.ks[2]);
+        sK.lstore(stg, ldsK);
+        sV.gload(stg, vrs, 0, p.vs[2]);
+        sV.lstore(stg, ldsV);
     }
     __syncthreads();
 #pragma unroll
@@ -148,10 +147,11 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
     const int vis = causal ? (row + coff) : 0x7fffffff;
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, k0 = t * 64;
-        sK.gload(stK, krs, k0 + 64, p.ks[2]);
-        sV.gload(stV, vrs, k0 + 64, p.vs[2]);
+        sK.gload(stg, krs, k0 + 64, p.ks[2]);
         const char* tK = ldsK + buf * TILEB;
         const char* tV = ldsV + buf * TILEB;
+        // LDS addresses from a fresh copy of the lane id per tile: hoisted out of the loop, the swizzled addresses of a tile's reads are what spilled
+        const int lane_f = fresh_lane_id(), l31 = lane_f & 31, hi = lane_f >> 5;
         f32x16 sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -162,6 +162,14 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
                 const f32x4 kf = lds_row4<D>(tK, kb * 32 + l31, 2 * c + hi);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sacc[kb] = mfma32(kf[e], qf[c][e], sacc[kb]);
+                if (D >= 128 && (c & 3) == 3) asm volatile("" ::: "memory");
+            }
+            // the other buffers were last read before the barrier that ended the previous tile: the staged rows go there as soon as a chain is done
+            if (kb == 0) {
+                sK.lstore(stg, ldsK + (buf ^ 1) * TILEB);
+                sV.gload(stg, vrs, k0 + 64, p.vs[2]);
+            } else {
+                sV.lstore(stg, ldsV + (buf ^ 1) * TILEB);
             }
         }
         // online softmax_n (log2 domain), exact every tile: the matrix pipe is the bottleneck here, not the VALU
@@ -215,9 +223,8 @@ __global__ void __launch_bounds__(256) fasn_f32_fwd_kernel(const FwdParams p) {
                 for (int d = 0; d < DB; ++d) {
                     const float vf = lds_elem32<D>(tV, kb * 32 + acc_row(r, hi), d * 32 + l31);
                     oacc[d] = mfma32(vf, sacc[kb][r], oacc[d]);
+                    if (D >= 128 && d == DB - 1 && (r & 3) == 3) asm volatile("" ::: "memory");
                 }
-        sK.lstore(stK, ldsK + (buf ^ 1) * TILEB);
-        sV.lstore(stV, ldsV + (buf ^ 1) * TILEB);
         __syncthreads();
     }
     const float l_tot = sum_across_halves(l_run);
@@ -305,17 +312,17 @@ __global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
     St sK, sV;
     sK.init(tid, p.ks[2]);
     sV.init(tid, p.vs[2]);
-    u32x4 stK[St::NLD], stV[St::NLD];
+    u32x4 stg[St::NLD];   // one staging set: the next tile's K rows travel during the first S / dP chain, its V rows during the second
     f32x16 dqacc[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[d][r] = 0.f;
     if (ntiles > 0) {
-        sK.gload(stK, krs, 0, p.ks[2]);
-        sV.gload(stV, vrs, 0, p.vs[2]);
-        sK.lstore(stK, ldsK);
-        sV.lstore(stV, ldsV);
+        sK.gload(stg, krs, 0, p.ks[2]);
+        sK.lstore(stg, ldsK);
+        sV.gload(stg, vrs, 0, p.vs[2]);
+        sV.lstore(stg, ldsV);
     }
     __syncthreads();
 #pragma unroll
@@ -328,10 +335,11 @@ __global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
     const int vis = causal ? (row + coff) : 0x7fffffff;
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, k0 = t * 64;
-        sK.gload(stK, krs, k0 + 64, p.ks[2]);
-        sV.gload(stV, vrs, k0 + 64, p.vs[2]);
+        sK.gload(stg, krs, k0 + 64, p.ks[2]);
         const char* tK = ldsK + buf * TILEB;
         const char* tV = ldsV + buf * TILEB;
+        // LDS addresses from a fresh copy of the lane id per tile: hoisted out of the loop, the swizzled addresses of a tile's reads are what spilled
+        const int lane_f = fresh_lane_id(), l31 = lane_f & 31, hi = lane_f >> 5;
         f32x16 sacc[2], pacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -346,6 +354,14 @@ __global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
                     sacc[kb] = mfma32(kf[e], qf[c][e], sacc[kb]);
                     pacc[kb] = mfma32(vf[e], dof[c][e], pacc[kb]);
                 }
+                if (D >= 128 && (c & 3) == 3) asm volatile("" ::: "memory");
+            }
+            // the other buffers were last read before the barrier that ended the previous tile: the staged rows go there as soon as a chain is done
+            if (kb == 0) {
+                sK.lstore(stg, ldsK + (buf ^ 1) * TILEB);
+                sV.gload(stg, vrs, k0 + 64, p.vs[2]);
+            } else {
+                sV.lstore(stg, ldsV + (buf ^ 1) * TILEB);
             }
         }
 #pragma unroll
@@ -372,9 +388,8 @@ __global__ void __launch_bounds__(256) fasn_f32_dq_kernel(const BwdParams bp) {
                 for (int d = 0; d < DB; ++d) {
                     const float kt = lds_elem32<D>(tK, kb * 32 + acc_row(r, hi), d * 32 + l31);
                     dqacc[d] = mfma32(kt, sacc[kb][r], dqacc[d]);
+                    if (D >= 128 && d == DB - 1 && (r & 3) == 3) asm volatile("" ::: "memory");
                 }
-        sK.lstore(stK, ldsK + (buf ^ 1) * TILEB);
-        sV.lstore(stV, ldsV + (buf ^ 1) * TILEB);
         __syncthreads();
     }
     if (ok) {
@@ -435,12 +450,15 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
     }
     f32x4 kf[KC], vf[KC];
     const bool ok = key < p.Sk;
+    {   // the lane's K / V row as range-checked buffer loads (rows behind the last key read as zero; `ok` covers a length-1 sequence with row stride 0)
+        const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.k + (b * p.ks[0] + hk * p.ks[1]) * 4), 0, p.kbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.v + (b * p.vs[0] + hk * p.vs[1]) * 4), 0, p.vbytes, 0x00020000);
+        const unsigned ko = (unsigned)(key * (int)p.ks[2] * 4 + hi * 16), vo = (unsigned)(key * (int)p.vs[2] * 4 + hi * 16);
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        kf[c] = vf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-            kf[c] = *reinterpret_cast<const f32x4*>(p.k + (b * p.ks[0] + (h / p.kvg) * p.ks[1] + (int64_t)key * p.ks[2]) * 4 + (2 * c + hi) * 16);
-            vf[c] = *reinterpret_cast<const f32x4*>(p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1] + (int64_t)key * p.vs[2]) * 4 + (2 * c + hi) * 16);
+        for (int c = 0; c < KC; ++c) {
+            kf[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, ko + c * 32, 0, 0));
+            vf[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, vo + c * 32, 0, 0));
+            if (!ok) kf[c] = vf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qbase), 0, bp.qbytes, 0x00020000);
@@ -448,7 +466,7 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
     St sQ, sD;
     sQ.init(tid, p.qs[2]);
     sD.init(tid, bp.dos[2]);
-    u32x4 stQ[St::NLD], stD[St::NLD];
+    u32x4 stg[St::NLD];   // one staging set: a tile's Q rows travel during the first S / dP chain, its dO rows during the second
     float stL = 0.f, stX = 0.f;
     auto stats_gload = [&](int row0) {
         if (tid < 64) {
@@ -469,11 +487,11 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
         }
     };
     if (tq0 < ntq) {
-        sQ.gload(stQ, qrs, tq0 * 64, p.qs[2]);
-        sD.gload(stD, drs, tq0 * 64, bp.dos[2]);
+        sQ.gload(stg, qrs, tq0 * 64, p.qs[2]);
         stats_gload(tq0 * 64);
-        sQ.lstore(stQ, ldsQ);
-        sD.lstore(stD, ldsDO);
+        sQ.lstore(stg, ldsQ);
+        sD.gload(stg, drs, tq0 * 64, bp.dos[2]);
+        sD.lstore(stg, ldsDO);
         stats_lstore(0);
     }
     __syncthreads();
@@ -484,13 +502,14 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
     }
     for (int tq = tq0; tq < ntq; ++tq) {
         const int buf = (tq - tq0) & 1, r0 = tq * 64;
-        sQ.gload(stQ, qrs, r0 + 64, p.qs[2]);
-        sD.gload(stD, drs, r0 + 64, bp.dos[2]);
+        sQ.gload(stg, qrs, r0 + 64, p.qs[2]);
         stats_gload(r0 + 64);
         const char* tQ = ldsQ + buf * TILEB;
         const char* tD = ldsDO + buf * TILEB;
         const float* tL = ldsLse + buf * 64;
         const float* tX = ldsDlt + buf * 64;
+        // LDS addresses from a fresh copy of the lane id per tile: hoisted out of the loop, the 16 + 16 swizzled addresses of a tile's reads are what spilled
+        const int lane_f = fresh_lane_id(), l31 = lane_f & 31, hi = lane_f >> 5;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 sacc, pacc;
@@ -505,13 +524,24 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
                     sacc = mfma32(qa[e], kf[c][e], sacc);   // S[q][key]
                     pacc = mfma32(da[e], vf[c][e], pacc);   // dP[q][key]
                 }
+                if (D >= 128 && (c & 3) == 3) asm volatile("" ::: "memory");
+            }
+            // the other buffer was last read before the barrier that ended the previous tile: the staged rows go there as soon as the chain is done
+            if (qb == 0) {
+                sQ.lstore(stg, ldsQ + (buf ^ 1) * TILEB);
+                sD.gload(stg, drs, r0 + 64, bp.dos[2]);
+            } else {
+                sD.lstore(stg, ldsDO + (buf ^ 1) * TILEB);
+                stats_lstore(buf ^ 1);
             }
             // dropout in passes of their own behind a wave-uniform branch (see the forward): dP is dropped and scaled in front of the element
             // pass, the weights that feed dV behind it (dS uses the undropped P); the keep bits are computed twice - the fp32 dropout path is
             // the reference's test grid, not a hot path
             if (GEN && p.drop_thr) {
+                int r0a = r0 + qb * 32;   // (opaque copies here and below: otherwise the hash inputs of all four passes of a tile are computed at its top and parked in scratch)
+                asm volatile("" : "+s"(r0a));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pacc[r] *= fdrop.keep(bh, r0 + qb * 32 + acc_row(r, hi), key) ? p.drop_scale : 0.f;
+                for (int r = 0; r < 16; ++r) pacc[r] *= fdrop.keep(bh, r0a + acc_row(r, hi), key) ? p.drop_scale : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -524,10 +554,13 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
                 pv = show ? pv : 0.f;
                 sacc[r] = pv;
                 pacc[r] = pv * (pacc[r] - tX[rr]);      // dS uses the undropped P
+                if (GEN && D >= 128 && (r & 3) == 3) asm volatile("" ::: "memory");   // (keeps the per-element mask / bias loads of four rows together instead of all sixteen in flight)
             }
             if (GEN && p.drop_thr) {
+                int r0b = r0 + qb * 32;
+                asm volatile("" : "+s"(r0b));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[r] *= fdrop.keep(bh, r0 + qb * 32 + acc_row(r, hi), key) ? p.drop_scale : 0.f;   // dropped weights feed dV
+                for (int r = 0; r < 16; ++r) sacc[r] *= fdrop.keep(bh, r0b + acc_row(r, hi), key) ? p.drop_scale : 0.f;   // dropped weights feed dV
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -538,11 +571,9 @@ __global__ void __launch_bounds__(256) fasn_f32_dkdv_kernel(const BwdParams bp) 
                     const float qt = lds_elem32<D>(tQ, rr, d * 32 + l31);
                     dvacc[d] = mfma32(dot, sacc[r], dvacc[d]);
                     dkacc[d] = mfma32(qt, pacc[r], dkacc[d]);
+                    if (D >= 128 && d == DB - 1 && (r & 3) == 3) asm volatile("" ::: "memory");
                 }
         }
-        sQ.lstore(stQ, ldsQ + (buf ^ 1) * TILEB);
-        sD.lstore(stD, ldsDO + (buf ^ 1) * TILEB);
-        stats_lstore(buf ^ 1);
         __syncthreads();
     }
     }   // query heads of the group

@@ -19,7 +19,11 @@ static int launch_ws256(FwdParams p, hipStream_t s) {
 }
 template <typename Tag>
 static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
-    if (p.drop_thr) return launch_fwd_one<Tag, 256, 1, MODE_GENERAL_SLOW, 1, 4, 0, 0, 1, 2>(p, s);   // dropout: the element-load kernel
+    if (p.drop_thr) {   // dropout (round 6): the vector general instantiation whenever the call's mask / bias rows move as vectors (or there is no operand)
+        const int md = (l.mode == MODE_BIAS_KEYPAD || l.mode == MODE_KEYPAD) ? p.keypad_fallback : l.mode;
+        if (md == MODE_GENERAL_SLOW) return launch_fwd_one<Tag, 256, 1, MODE_GENERAL_SLOW, 1, 4, 0, 0, 1, 2>(p, s);   // the element-load kernel
+        return launch_fwd_one<Tag, 256, 1, MODE_GENERAL, 1, 4, 0, 2, 1, 2>(p, s);
+    }
     const int mode = l.mode == MODE_BIAS_KEYPAD ? p.keypad_fallback : l.mode;   // bias + key padding: the dense-mask view of the same mask
 #ifdef FASN_DEV_VARIANTS
     if (l.variant == 1) {   // A/B: the round-3 feature-half kernels

@@ -156,7 +156,7 @@ def _cache():
 
 
 class _Plan:
-    __slots__ = ("fwd", "fwd_ws", "bwd", "bwd_ws", "path")
+    __slots__ = ("fwd", "fwd_ws", "bwd", "bwd_ws", "path", "bwd_path")
 
 
 _WARNED_SLOW = set()
@@ -185,6 +185,7 @@ def _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p):
             pl.fwd_ws = lib.fasn_fwd_workspace_bytes(pl.fwd)     # > 0: short-query / long-key shape, keys split over workgroups
             pl.bwd_ws = lib.fasn_bwd_workspace_bytes(pl.bwd)     # 0 with libfasn.so (the ABI keeps the hook for plans that need scratch)
             pl.path = lib.fasn_fwd_path(pl.fwd)
+            pl.bwd_path = None   # asked at the first backward (fasn_bwd_path wants the backward's real argument block)
         if pl.path == _lib.FASN_PATH_ELEMENT:   # same results, 3-5 x slower: say so once per kind of call instead of silently
             why = (_sig(mask), _sig(bias), dropout_p > 0.0)
             if why not in _WARNED_SLOW:
@@ -192,7 +193,7 @@ def _plan_for(q, k, v, mask, bias, n, scale, causal, dropout_p):
                 import warnings
                 warnings.warn("flash_attention_n: this call takes the element-load kernels (3-5x slower than the vector path): "
                               "a mask / bias whose rows are not aligned vectors (unaligned or strided rows; an fp32 bias with 16-bit q at head dim 256, under dropout or with rows not 16-byte aligned), "
-                              "scale <= 0 with a bias, fp16 with a very large scale, or dropout at head dim 256. "
+                              "scale <= 0 with a bias, or fp16 with a very large scale. "
                               "See fasn_fwd_path in include/fasn.h.", RuntimeWarning, stacklevel=4)
         c[key] = pl
     return pl
@@ -304,6 +305,16 @@ class _FlashAttentionSoftmaxN(torch.autograd.Function):
                 a.dbias = _view4(dbias)
         else:
             a.dbias.ptr = None
+        if pl.bwd_path is None:   # once per cached call signature
+            pl.bwd_path = lib.fasn_bwd_path(a)
+            if pl.bwd_path == _lib.FASN_PATH_ELEMENT and pl.path != _lib.FASN_PATH_ELEMENT:
+                why = ("bwd", _sig(mask), _sig(bias), D)
+                if why not in _WARNED_SLOW:
+                    _WARNED_SLOW.add(why)
+                    import warnings
+                    warnings.warn("flash_attention_n backward: dQ / dK / dV of this call take the element-load kernels (3-5x slower) although its forward "
+                                  "is on the vector path. See fasn_bwd_path in include/fasn.h.", RuntimeWarning, stacklevel=2)
+
         def launch():
             if pl.bwd_ws:
                 ws = torch.empty(pl.bwd_ws, dtype=torch.uint8, device=dev)

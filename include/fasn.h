@@ -137,12 +137,12 @@ int fasn_supported(int32_t dtype, int32_t D, int32_t Dv);
 int fasn_fwd(const fasn_fwd_args* args, fasn_stream_t stream);
 
 /*
- * Which kernel family `args` is routed to (ABI 4; the backward of the same call takes the same family): a non-negative
+ * Which kernel family `args` is routed to (ABI 4; the backward: fasn_bwd_path below - the same family except at head dim 256): a non-negative
  * FASN_PATH_* value, or a negative FASN_E* code for arguments fasn_fwd would refuse. Every family gives the same results; they
  * differ in speed. FASN_PATH_ELEMENT is the one to know about: masks / biases whose rows cannot be moved in aligned vector
  * pieces (unaligned or strided rows, key stride != 1; an fp32 bias next to 16-bit q at head dim 256, under dropout, or with rows
  * that are not 16-byte aligned - at head dims <= 128 an aligned fp32 bias takes the vector family since ABI 5), scale <= 0 with a bias, fp16 with
- * scale*log2(e) > 8, and dropout at head dim 256 take per-element loads and run 3-5 x slower than the vector path. Nothing is launched. (The reference has no counterpart: its SDPA backends are picked inside torch.)
+ * scale*log2(e) > 8 take per-element loads and run 3-5 x slower than the vector path (ABI 6: dropout at head dim 256 no longer does - it runs the vector general kernels, and reports FASN_PATH_VECTOR, whenever the call's operands allow). Nothing is launched. (The reference has no counterpart: its SDPA backends are picked inside torch.)
  */
 #define FASN_PATH_PLAIN 0       /* no mask / bias (causal or not) */
 #define FASN_PATH_KEYPAD 1      /* key-padding mask as per-tile visibility bits */
@@ -194,6 +194,13 @@ int fasn_bwd(const fasn_bwd_args* args, fasn_stream_t stream);
 #define FASN_PLAN_BWD 1
 #define FASN_PLAN_FWD_WS 2
 int fasn_launch_plan(const fasn_bwd_args* args, int32_t which, char* buf, size_t cap);
+
+/*
+ * Which kernel family the BACKWARD of a call takes (ABI 6): the value fasn_fwd_path gives for args->fwd, except that FASN_PATH_ELEMENT is
+ * returned whenever the recorded backward plan contains an element-load kernel - today the two only differ through operands the backward's kernels cannot move as vectors although the forward's can (none known: since round 6 the head dim 256 backward
+ * has vector instantiations for dense masks and 16-bit biases too); kept so that the front end's slow-path warning follows the backward's launch table, not an assumption about it. Same argument rules as fasn_launch_plan; nothing is launched.
+ */
+int fasn_bwd_path(const fasn_bwd_args* args);
 
 /*
  * Stand-alone softmax_n over the last dimension of a [rows, cols] matrix (row stride in elements,

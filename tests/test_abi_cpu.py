@@ -172,6 +172,34 @@ def test_fwd_path_query(pkg):
     assert lib.fasn_fwd_path(with_views(mask=(64, 64, 8, 3))) == 4                                 # key stride != 1
 
 
+def test_bwd_path_query(pkg):
+    """fasn_bwd_path = the forward's family, except where the recorded backward plan holds element-load kernels: head dim 256 with a bias / dense mask"""
+    from baseline_plans import bwd_args, _view
+    lib = pkg._lib.load()
+    for name, want in (("m0", 0), ("c3", 0), ("c4", 3)):
+        a = bwd_args(pkg, name)
+        assert lib.fasn_bwd_path(a) == want == lib.fasn_fwd_path(a.fwd), name
+    a = bwd_args(pkg, "c4")   # bias + key padding at head dim 256: the vector general kernels in both directions since round 6 (round 5: element loads backward)
+    f = a.fwd
+    f.D = f.Dv = 256
+    dense = (f.H * f.Sq * 256, f.Sq * 256, 256, 1)
+    for v in (f.q, f.k, f.v, f.o, a.dout, a.dq, a.dk, a.dv):
+        _view(v, dense)
+    assert lib.fasn_fwd_path(f) == 2 and lib.fasn_bwd_path(a) == 2
+    plan = pkg._lib.launch_plan_described(a, pkg._lib.FASN_PLAN_BWD)
+    assert not any("element-load" in row[0] for row in plan) and any("bias+mask" in row[0] for row in plan), plan
+    f.dropout_p = 0.1     # dropout too
+    assert lib.fasn_fwd_path(f) == 2 and lib.fasn_bwd_path(a) == 2
+    assert all("DROP=1" in row[0] for row in pkg._lib.launch_plan_described(a, pkg._lib.FASN_PLAN_BWD) if "delta" not in row[0])
+    f.bias.stride[2] += 1   # bias rows that are not 16-byte movable: element loads, both directions
+    assert lib.fasn_fwd_path(f) == 4 and lib.fasn_bwd_path(a) == 4
+    f.bias.stride[2] -= 1
+    f.dropout_p = 0.0
+    f.bias.ptr = None     # key padding alone: the two-wave kernels in both directions
+    assert lib.fasn_fwd_path(f) == 1 and lib.fasn_bwd_path(a) == 1
+    assert lib.fasn_bwd_path(None) == -1
+
+
 def test_front_end_refuses_cpu_and_unsupported(pkg):
     q = torch.zeros(1, 1, 4, 32)
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -60,11 +60,19 @@ def test_baseline_kernels_do_not_spill(table, pkg):
     assert not bad, f"kernels reachable from a BASELINE config spill: {bad}"
 
 
+def _to_memory(v):
+    """Spilled vector registers that reach scratch MEMORY. A kernel that runs one wave per SIMD has 256 accumulation registers next to its 256
+    vector registers and hipcc parks values there (`v_accvgpr_write` / `_read`, one instruction, no memory, no wait): the code object's metadata
+    counts those as spilled registers too, with a scratch size of zero (round 6: fasn_fwd_kernel<*, 256, ...general> and the plain / causal
+    fasn_f32_dkdv_kernel<128> are such kernels). The gate is about the `s_waitcnt vmcnt(0)` of a scratch reload, so it counts those as 0."""
+    return v.get("spill", 0) if v.get("scratch", 0) > 0 else 0
+
+
 def test_no_kernel_spills_more_than_recorded(table):
     allow = json.load(open(ALLOW))
-    worse = {n: (v.get("spill", 0), allow.get(n, 0)) for n, v in table.items() if v.get("spill", 0) > allow.get(n, 0)}
-    spilling = sorted(((v.get("spill", 0), n) for n, v in table.items() if v.get("spill", 0)), reverse=True)
-    print(f"\n{len(table)} kernels, {len(spilling)} with spilled VGPRs (allowance file: {len(allow)})")
+    worse = {n: (_to_memory(v), allow.get(n, 0)) for n, v in table.items() if _to_memory(v) > allow.get(n, 0)}
+    spilling = sorted(((_to_memory(v), n) for n, v in table.items() if _to_memory(v)), reverse=True)
+    print(f"\n{len(table)} kernels, {len(spilling)} with vector registers spilled to scratch memory (allowance file: {len(allow)})")
     for s, n in spilling:
         print(f"  spill {s:4d}  {n[9:120]}")
     assert not worse, f"spill regressions (kernel: (now, allowed)): {worse}"

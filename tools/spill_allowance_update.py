@@ -19,7 +19,7 @@ def main():
     old = json.load(open(ALLOW))
     new, worse = {}, []
     for n, v in sorted(table.items()):
-        s = v.get("spill", 0)
+        s = v.get("spill", 0) if v.get("scratch", 0) > 0 else 0   # (registers parked in accumulation registers - scratch size 0 - are not memory traffic: tests/test_spill_gate.py)
         if not s:
             continue
         if s > old.get(n, 0):
