@@ -6,11 +6,15 @@
 // zero-range descriptor / an all-ones word), key padding rides the plain kernel, everything else the element-load kernel.
 #include "fasn_launch.h"
 #include "fasn_fwd_ws256.h"
+#ifndef FASN_D256_GEN_WS
+#define FASN_D256_GEN_WS 1
+#endif
 namespace fasn {
 // plain / causal: the two-wave kernel (fasn_fwd_ws256.h, round 4): 128-row workgroups of 8 waves, no score computed twice
 template <typename Tag, int MODE>
 static int launch_ws256(FwdParams p, hipStream_t s) {
-    constexpr int smem = ws256_smem_bytes();
+    constexpr int smem = ws256_smem_bytes(MODE);
+    static_assert(smem <= 160 * 1024, "two-wave D = 256 forward: LDS");
     p.nqblk = (p.Sq + 127) / 128;
     constexpr auto kern = &fasn_fwd_ws256_kernel<Tag, MODE>;
     ensure_smem<kern>(smem);
@@ -36,7 +40,9 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
         case MODE_PLAIN: return launch_ws256<Tag, MODE_PLAIN>(p, s);
         case MODE_CAUSAL: return launch_ws256<Tag, MODE_CAUSAL>(p, s);
         case MODE_KEYPAD: return launch_ws256<Tag, MODE_KEYPAD>(p, s);
-        case MODE_GENERAL: case MODE_GENERAL_B: case MODE_GENERAL_M: return launch_fwd_one<Tag, 256, 1, MODE_GENERAL, 1, 4, 0, 2, 0, 2>(p, s);
+        case MODE_GENERAL: case MODE_GENERAL_B: case MODE_GENERAL_M:   // dense mask and / or 16-bit bias: the two-wave kernel with per-wave images (round 6; FASN_D256_GEN_WS=0: the feature-half kernel)
+            if (FASN_D256_GEN_WS) return launch_ws256<Tag, MODE_GENERAL>(p, s);
+            return launch_fwd_one<Tag, 256, 1, MODE_GENERAL, 1, 4, 0, 2, 0, 2>(p, s);
         default: return launch_fwd_one<Tag, 256, 1, MODE_GENERAL_SLOW, 1, 4, 0, 0, 0, 2>(p, s);
     }
 }

@@ -14,8 +14,12 @@
 // that ends iteration u. K / V arrive by LDS-DMA in units of 32 keys (16 KiB images [32][256], swizzled like every tile), K and V in rings
 // of four, both requested two blocks ahead of their first reader (vmcnt counts in order: a deeper K ring behind a shallow V ring would
 // be drained by the wait for V anyway); one barrier per block. Plain, causal and key-padding launches (MODE_KEYPAD: wave A takes
-// the 32 visibility bits of a key block from a per-workgroup word table and the blocks behind the last visible key are not walked);
-// the bias / dropout modes stay on the feature-half kernels.
+// the 32 visibility bits of a key block from a per-workgroup word table and the blocks behind the last visible key are not walked).
+// MODE_GENERAL (round 6: a dense boolean mask and / or a 16-bit additive bias whose rows move as vectors; either may be absent): wave A keeps a
+// private ring of two images of its [32 rows][32 keys] - 2 KiB of bias, 1 KiB of mask bytes, three LDS-DMA requests, asked for two blocks
+// ahead right after the block's image has been read into registers - and starts its score accumulator at bias*log2e (-inf where the mask
+// byte is clear) instead of zero; nothing else changes, wave B does not know. The 24 KiB of images are paid for with the fourth V slot
+// (V is then requested one block ahead of the block wave B is working on). Dropout stays on the feature-half kernels.
 #pragma once
 #include "fasn_fwd_kernel.h"
 
@@ -23,23 +27,31 @@ namespace fasn {
 
 constexpr int W256_NK = 4, W256_NV = 4;           // K / V ring slots
 constexpr int W256_UNIT = 32 * 256 * 2;           // one 32-key image
-constexpr int ws256_smem_bytes() { return (W256_NK + W256_NV) * W256_UNIT + 2 * 4 * 2048 + 2 * 4 * 256 + kFwdKpMaxTiles * 8; }
+constexpr int W256_IMG = 3072;                    // MODE_GENERAL: one image slot of an A wave (2 KiB bias + 1 KiB mask)
+constexpr int ws256_smem_bytes(int mode = MODE_KEYPAD) {
+    return mode == MODE_GENERAL ? (W256_NK + 3) * W256_UNIT + 2 * 4 * 2048 + 2 * 4 * 256 + 4 * 2 * W256_IMG
+                                : (W256_NK + W256_NV) * W256_UNIT + 2 * 4 * 2048 + 2 * 4 * 256 + kFwdKpMaxTiles * 8;
+}
 
 template <typename Tag, int MODE>
 __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams p) {
-    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL || MODE == MODE_KEYPAD, "two-wave D = 256 forward: plain, causal, key padding");
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL || MODE == MODE_KEYPAD || MODE == MODE_GENERAL, "two-wave D = 256 forward: plain, causal, key padding, vector mask / bias");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     constexpr int D = 256, KS = 16, DB = 8, BM = 128, KU = 32;
     constexpr bool KP = MODE == MODE_KEYPAD;   // a boolean mask over (batch, head, key), with or without the causal flag
-    const bool causal = MODE == MODE_CAUSAL || (KP && p.causal != 0);
+    constexpr bool GEN = MODE == MODE_GENERAL; // dense mask and / or 16-bit bias as per-wave LDS images
+    constexpr int NV = GEN ? 3 : W256_NV;      // V ring slots
+    constexpr int NIMG = GEN ? 3 : 0;          // image requests of an A wave per block
+    const bool causal = MODE == MODE_CAUSAL || ((KP || GEN) && p.causal != 0);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsK = smem;                                        // [W256_NK][UNIT]
     char* const ldsV = smem + W256_NK * W256_UNIT;                  // [W256_NV][UNIT]
-    char* const ldsP = smem + (W256_NK + W256_NV) * W256_UNIT;      // [2][4 row blocks][2 KiB]
+    char* const ldsP = smem + (W256_NK + NV) * W256_UNIT;           // [2][4 row blocks][2 KiB]
     float* const ldsA = reinterpret_cast<float*>(ldsP + 2 * 4 * 2048);   // [2][4][64] rescale factor of the lane's row
     uint64_t* const ldsKP = reinterpret_cast<uint64_t*>(ldsP + 2 * 4 * 2048 + 2 * 4 * 256);   // [kFwdKpMaxTiles] visibility words of 64 keys (key-padding mode)
+    char* const ldsI = ldsP + 2 * 4 * 2048 + 2 * 4 * 256;           // [4 A waves][2][W256_IMG] bias + mask images (MODE_GENERAL; no visibility words there)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -90,11 +102,43 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
         for (int i = 0; i < 2; ++i) lds_dma16(vrw, __builtin_amdgcn_readfirstlane(ldsV_w + slot * W256_UNIT + i * 8192), voffV[i], (uint32_t)u * (uint32_t)(KU * (int)p.vs[2] * 2));
     };
 
-    // ---- prologue: the first K / V units (iteration u requests K unit u + 3 and V unit u + 2; before the loop: K 0..2, V 0..1)
+    // ---- MODE_GENERAL: the images of this A wave. Bias: [32 rows][64 B] as 128 pieces of 16 bytes (8 keys), piece chunk ^ swz_f<32>(row) of a row
+    // in place `chunk` (the forward's dense-mask image layout); mask: [32 rows][32 B] row major, 64 pieces. A lane owns a ROW: its accumulator
+    // registers 4g .. 4g+3 are keys 8g + 4hi + 0..3 of the block - 8 bytes of the bias row, 4 of the mask row.
+    u32x4 brw = {0u, 0u, 0u, 0u}, mrw = {0u, 0u, 0u, 0u};
+    unsigned bvo[2] = {0u, 0u}, mvo = 0u;
+    if (GEN) {
+        brw = make_rsrc_words(p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q, p.bias ? p.bias_bytes : 0u);
+        mrw = make_rsrc_words(p.mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q, p.mask ? p.mask_bytes : 0u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = i * 64 + lane, r = sl >> 2, c = (sl & 3) ^ swz_f<32>(r);
+            bvo[i] = (unsigned)(((qw0 + r) * (int)p.bs[2] + c * 8) * 2);
+        }
+        mvo = (unsigned)((qw0 + (lane >> 1)) * (int)p.ms[2] + (lane & 1) * 16);
+    }
+    char* const img = ldsI + rbw * (2 * W256_IMG);
+    const uint32_t img_a = lds_addr(img);
+    auto img_dma = [&](int u, int slot) {   // 3 requests; blocks past the last key are out of the descriptors' range: zeros, no traffic
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16(brw, __builtin_amdgcn_readfirstlane(img_a + slot * W256_IMG + i * 1024), bvo[i], (uint32_t)u * (uint32_t)(KU * 2));
+        lds_dma16(mrw, __builtin_amdgcn_readfirstlane(img_a + slot * W256_IMG + 2048), mvo, (uint32_t)u * (uint32_t)KU);
+    };
+    const uint32_t nomask = (GEN && p.mask == nullptr) ? 0x01010101u : 0u;   // no mask operand: every byte reads as set
+    const char* const img_rd_b = img + l31 * 64 + hi * 8;   // + ((g ^ swz) << 4)
+    const char* const img_rd_m = img + 2048 + l31 * 32 + hi * 4;   // + 8 g
+    const int img_swz = swz_f<32>(l31);
+
+    // ---- prologue: the first K / V units (iteration u requests K unit u + 3 and V unit u + 2; before the loop: K 0..2, V 0..1.
+    // MODE_GENERAL, three V slots: iteration u requests V unit u + 1; before the loop: V 0, and the images of blocks 0 and 1)
 #pragma unroll
     for (int u = 0; u < W256_NK - 1; ++u) k_dma(u, u);
     v_dma(0, 0);
-    v_dma(1, 1);
+    if (!GEN) v_dma(1, 1);
+    if (GEN && role == 0) {
+        img_dma(0, 0);
+        img_dma(1, 1);
+    }
     // softmax_n state of the lane's row: the sink column (logit 0, weight n) is the start value; each half-wave sums its own 16 keys
     // per block and the halves are merged at the end (the maximum is shared every block, so both halves scale alike)
     float m_run = p.n > 0.f ? 0.f : -INFINITY;
@@ -120,6 +164,15 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
     float* const aslot = ldsA + rbw * 64 + lane;            // + parity * 256
 
     // ---- wave A: key block u
+    u32x2 braw[4] = {};   // MODE_GENERAL: the lane's 16 bias values / 16 mask bytes of the block wave A is working on
+    uint32_t mraw[4] = {};
+    auto img_read = [&](int slot) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            braw[g] = *LDS_PTR(const u32x2, img_rd_b + slot * W256_IMG + ((g ^ img_swz) << 4));
+            mraw[g] = *LDS_PTR(const uint32_t, img_rd_m + slot * W256_IMG + 8 * g);
+        }
+    };
     auto block_a = [&](const int u, const int kslot, const vec8 (&qf)[KS]) {
         bool skip, need_mask;
         uint32_t kpb;
@@ -135,6 +188,14 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        if constexpr (GEN) {   // start values from the block's image (the caller has read it: braw / mraw)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t w = braw[r >> 2][(r & 3) >> 1];
+                const float bv = E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))) * kLog2e;
+                sacc[r] = (((mraw[r >> 2] | nomask) >> (8 * (r & 3))) & 0xffu) ? bv : -INFINITY;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const vec8 kf = lds_read_rowfrag<E, D>(tK, l31, s, hi);
@@ -210,13 +271,32 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
     auto requests = [&](int u) {
         // (past the end of the WALK - which a causal bound or a key-padding trim may have shortened - ask for the unit behind the last KEY:
         // out of range, zero fill, no traffic; the request counts stay uniform)
-        k_dma(u + 3 < nu ? u + 3 : nu_all, (u + 3) & 3);
-        v_dma(u + 2 < nu ? u + 2 : nu_all, (u + 2) & 3);
+        if constexpr (GEN) {
+            // V first, K last: vmcnt counts in order, and what the barrier at the end of this iteration has to publish - V unit u, the images of
+            // block u + 1 (both asked for in iteration u - 1) - then sits in front of K unit u + 2, which may stay in flight with this iteration's
+            v_dma(u + 1 < nu ? u + 1 : nu_all, (u + 1) % 3);
+            if (role == 0) {
+                if (u < nu) img_read(u & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before its slot is asked for again
+                img_dma(u + 2 < nu ? u + 2 : nu_all, u & 1);
+            }
+            k_dma(u + 3 < nu ? u + 3 : nu_all, (u + 3) & 3);
+        } else {
+            k_dma(u + 3 < nu ? u + 3 : nu_all, (u + 3) & 3);
+            v_dma(u + 2 < nu ? u + 2 : nu_all, (u + 2) & 3);
+        }
     };
-    auto close = [&]() {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    auto close = [&](auto ROLE_) {
+        if constexpr (GEN) {
+            if constexpr (decltype(ROLE_)::value == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NIMG) : "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
         __syncthreads();
     };
+    using RoleA = std::integral_constant<int, 0>;
+    using RoleB = std::integral_constant<int, 1>;
     if (KP) kp_build_words(ldsKP, p.mask ? p.mask + (b * p.ms[0] + h * p.ms[1]) : nullptr, p.Sk, (p.Sk + 63) / 64, tid, 512);   // published by the first barrier below
     auto trim = [&]() {   // key-padding: blocks behind the last visible key are not walked (every wave finds the same one)
         if (!KP) return;
@@ -256,7 +336,7 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
         for (int u = 0; u <= nu; ++u) {
             requests(u);
             if (u < nu) block_a(u, u & 3, qf);
-            close();
+            close(RoleA{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const float l_tot = sum_across_halves(l_run);
@@ -277,8 +357,8 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
         trim();
         for (int u = 0; u <= nu; ++u) {
             requests(u);
-            if (u > 0) block_b(u - 1, (u - 1) & 3, oacc);
-            close();
+            if (u > 0) block_b(u - 1, GEN ? (u - 1) % 3 : (u - 1) & 3, oacc);
+            close(RoleB{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // 1 / l of every row is published

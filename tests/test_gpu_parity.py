@@ -897,7 +897,7 @@ def _oracle_dropout(q, k, v, do, keep, p_eff, **kw):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["plain", "causal", "bias+mask", "keypad", "bias", "keypad+causal"])
-@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("D", [32, 64, 128, 256])   # (256, round 6: the vector general kernels with dropout instead of the element-load kernels)
 def test_dropout_matches_oracle_with_explicit_mask(pkg, dev, D, mode, dtype):
     """reference: dropout(softmax_n(...)) @ v (functional.py:91-93, flash_attn.py:122). The kernels' keep bits are a pure
     function of (seed, b, h, row, key), mirrored on the host by dropout.keep_mask, so parity is exact up to rounding."""
