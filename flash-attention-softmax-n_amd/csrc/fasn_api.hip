@@ -39,7 +39,7 @@ static size_t describe_kernel(const char* name, size_t n, char* out, size_t cap)
         {"fasn_bwd_dkdv_pipe_kernel", "T M !DROP"},
         {"fasn_bwd_dq_ws256_kernel", "T M"},
         {"fasn_bwd_dkdv_ws256_kernel", "T M !GQA"},
-        {"fasn_fwd_ws256_kernel", "T M"},
+        {"fasn_fwd_ws256_kernel", "T M !DROP"},
         {"fasn_bwd_delta_kernel", "T D"},
         {"fasn_fwd_combine_kernel", "T D"},
         {"fasn_bwd_dbias_ws_kernel", "T D"},

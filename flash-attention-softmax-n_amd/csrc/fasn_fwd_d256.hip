@@ -11,12 +11,12 @@
 #endif
 namespace fasn {
 // plain / causal: the two-wave kernel (fasn_fwd_ws256.h, round 4): 128-row workgroups of 8 waves, no score computed twice
-template <typename Tag, int MODE>
+template <typename Tag, int MODE, int DROP = 0>
 static int launch_ws256(FwdParams p, hipStream_t s) {
     constexpr int smem = ws256_smem_bytes(MODE);
     static_assert(smem <= 160 * 1024, "two-wave D = 256 forward: LDS");
     p.nqblk = (p.Sq + 127) / 128;
-    constexpr auto kern = &fasn_fwd_ws256_kernel<Tag, MODE>;
+    constexpr auto kern = &fasn_fwd_ws256_kernel<Tag, MODE, DROP>;
     ensure_smem<kern>(smem);
     FASN_LAUNCH(kern, dim3((unsigned)(p.nqblk * p.B * p.H)), dim3(512), smem, s, p);
     return launch_rc();
@@ -26,6 +26,7 @@ static int go(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
     if (p.drop_thr) {   // dropout (round 6): the vector general instantiation whenever the call's mask / bias rows move as vectors (or there is no operand)
         const int md = (l.mode == MODE_BIAS_KEYPAD || l.mode == MODE_KEYPAD) ? p.keypad_fallback : l.mode;
         if (md == MODE_GENERAL_SLOW) return launch_fwd_one<Tag, 256, 1, MODE_GENERAL_SLOW, 1, 4, 0, 0, 1, 2>(p, s);   // the element-load kernel
+        if (FASN_D256_GEN_WS) return launch_ws256<Tag, MODE_GENERAL, 1>(p, s);   // the two-wave kernel (per-wave images; keep bits on the packed weights)
         return launch_fwd_one<Tag, 256, 1, MODE_GENERAL, 1, 4, 0, 2, 1, 2>(p, s);
     }
     const int mode = l.mode == MODE_BIAS_KEYPAD ? p.keypad_fallback : l.mode;   // bias + key padding: the dense-mask view of the same mask

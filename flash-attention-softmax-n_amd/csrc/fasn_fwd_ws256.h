@@ -33,8 +33,12 @@ constexpr int ws256_smem_bytes(int mode = MODE_KEYPAD) {
                                 : (W256_NK + W256_NV) * W256_UNIT + 2 * 4 * 2048 + 2 * 4 * 256 + kFwdKpMaxTiles * 8;
 }
 
-template <typename Tag, int MODE>
+// DROP = 1 (MODE_GENERAL only - it serves every dropout call at this head dim, operands or not): wave A clears the dropped weights in the
+// PACKED pairs it hands to wave B (stream definition 2, fasn_common.h: DropBlock, the plain register layout); its row sums keep the undropped
+// weights and 1 / (1 - p) goes into the final 1 / l, as in fasn_fwd_kernel.h.
+template <typename Tag, int MODE, int DROP = 0>
 __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams p) {
+    static_assert(!DROP || MODE == MODE_GENERAL, "two-wave D = 256 forward: dropout through the general instantiation");
     static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL || MODE == MODE_KEYPAD || MODE == MODE_GENERAL, "two-wave D = 256 forward: plain, causal, key padding, vector mask / bias");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
@@ -160,6 +164,10 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
             need_mask = need_mask || kpb != ~0u;
         }
     };
+    const DropSeed dsd = DROP ? drop_seed(p.seed_lo, p.seed_hi, p.rng) : DropSeed{0u, 0u};
+    const DropThr dthr = drop_thr(DROP ? p.drop_thr : 1u);
+    const uint32_t drop_rh = drop_rh_of(hi);
+    const uint32_t drop_rb = DROP ? drop_row_base(dsd.lo, (uint32_t)bh, (uint32_t)row) : 0u;
     char* const pslot = ldsP + rbw * 2048 + lane * 16;      // + parity * 8192 (+ 1024 for the second half of the block)
     float* const aslot = ldsA + rbw * 64 + lane;            // + parity * 256
 
@@ -232,6 +240,14 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
         u32x4 w0, w1;
         __builtin_memcpy(&w0, &pfr[0], 16);
         __builtin_memcpy(&w1, &pfr[1], 16);
+        if constexpr (DROP != 0) {
+            const DropBlock<false> db(drop_rb, dsd.hi, (uint32_t)((u * KU) >> 4), hi, drop_rh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // dword e of half t2 = accumulator registers 8 t2 + 2 e, + 1
+                w0[e] &= db.keep_mask_pk(e, dthr);
+                w1[e] &= db.keep_mask_pk(4 + e, dthr);
+            }
+        }
         *LDS_PTR(u32x4, ps) = w0;
         *LDS_PTR(u32x4, ps + 1024) = w1;
         aslot[(u & 1) * 256] = alpha;
@@ -340,7 +356,7 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const float l_tot = sum_across_halves(l_run);
-        aslot[0] = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        aslot[0] = l_tot > 0.f ? (DROP ? p.drop_scale : 1.0f) / l_tot : 0.f;
         if (row_ok && p.lse != nullptr && hi == 0) {
             const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
             p.lse[(int64_t)bh * p.Sq + row] = l_tot > 0.f ? (m_use + __builtin_log2f(l_tot)) * kLn2 : -INFINITY;
