@@ -5,6 +5,9 @@
 // kernels (round 6), operands whose rows do not move as vectors the element-load kernels.
 #include "fasn_bwd_launch.h"
 #include "fasn_bwd_ws256.h"
+#ifndef FASN_D256_GEN_WS
+#define FASN_D256_GEN_WS 1
+#endif
 namespace fasn {
 // plain / causal without dropout or grouped K/V: the two-wave kernels of fasn_bwd_ws256.h (round 4): delta, dQ, dK/dV
 // MODE = the dQ kernel's; MODE_KEYPAD (a boolean mask over (batch, head, key), p.f.causal as it comes): the dK/dV kernel then is the
@@ -73,7 +76,24 @@ static int go(const BwdParams& p, int mode, hipStream_t s) {
         case MODE_KEYPAD: return launch_bwd_one<Tag, 256, 1, 1, MODE_KEYPAD, 1, 1, 0, 0, 2>(p, s);
         // dense masks / 16-bit bias with vector-movable rows (round 6): the one-wave vector kernels - the dK/dV kernel with ONE additive tile
         // (two of them next to four 32 KiB Q / dO buffers would need 161 KiB of LDS; round 5 sent these calls to the element-load kernels, 3 x slower)
-        case MODE_GENERAL: case MODE_GENERAL_B: case MODE_GENERAL_M: return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 0, 0, 2>(p, s);
+        case MODE_GENERAL: case MODE_GENERAL_B: case MODE_GENERAL_M:
+            if (FASN_D256_GEN_WS && p.dbias == nullptr) {   // dQ by the two-wave kernel with per-wave images (no dense dS store there); dK / dV by the one-wave vector kernel
+                const int nbh = p.f.B * p.f.H;
+                constexpr int RPB = 256 / (256 / 8);
+                const int64_t rows = (int64_t)nbh * p.f.Sq;
+                FASN_LAUNCH((fasn_bwd_delta_kernel<Tag, 256>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
+                constexpr int smem = bwd_dq_ws256_smem_bytes(MODE_GENERAL);
+                static_assert(smem <= 160 * 1024, "two-wave D = 256 dQ: LDS");
+                BwdParams q = p;
+                q.nblk = (p.f.Sq + 127) / 128;
+                constexpr auto kern = &fasn_bwd_dq_ws256_kernel<Tag, MODE_GENERAL>;
+                ensure_smem<kern>(smem);
+                FASN_LAUNCH(kern, dim3((unsigned)(q.nblk * nbh)), dim3(512), smem, s, q);
+                BwdParams r = p;
+                r.skip |= 2 | 4;   // dQ and delta are launched
+                return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 0, 0, 2>(r, s);
+            }
+            return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 0, 0, 2>(p, s);
         default: return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL_SLOW, 1, 1, 0, 0, 2>(p, s);
     }
 }

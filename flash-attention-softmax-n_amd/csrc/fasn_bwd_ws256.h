@@ -333,23 +333,35 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
 
 // ------------------------------------------------------------------------------------------------------------------ dQ
 constexpr int kDq256KpTiles = 1024;   // visibility words of 64 keys kept in LDS by the key-padding instantiation (8 KiB): Sk <= 65536
-constexpr int bwd_dq_ws256_smem_bytes() { return 2 * B256_RING * B256_UNIT + 2 * 4 * 2048 + kDq256KpTiles * 8; }
+constexpr int B256_IMG = 3072;            // MODE_GENERAL: one image slot of an A wave (2 KiB bias + 1 KiB mask), as in fasn_fwd_ws256.h
+constexpr int bwd_dq_ws256_smem_bytes(int mode = MODE_KEYPAD) {
+    return mode == MODE_GENERAL ? (B256_RING + 3) * B256_UNIT + 2 * 4 * 2048 + 4 * 2 * B256_IMG : 2 * B256_RING * B256_UNIT + 2 * 4 * 2048 + kDq256KpTiles * 8;
+}
 
+// MODE_GENERAL (round 6; a dense boolean mask and / or a 16-bit additive bias whose rows move as vectors, either may be absent; no dense dS store -
+// calls that want one keep the one-wave kernel): exactly the forward's scheme (fasn_fwd_ws256.h) - wave A keeps a private ring of two
+// [32 rows][32 keys] images (2 KiB bias, 1 KiB mask bytes; three LDS-DMA requests per unit, asked for two units ahead right after the unit's
+// image has been read into registers) and seeds S^T with bias*log2e - LSE*log2e (-inf where the mask byte is clear). The images are paid
+// for with the fourth V slot: wave B reads V one unit behind wave A's K, so V is requested one unit later at the same lead.
 template <typename Tag, int MODE>
 __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdParams bp) {
-    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL || MODE == MODE_KEYPAD, "two-wave D = 256 backward: plain, causal, key padding");
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_CAUSAL || MODE == MODE_KEYPAD || MODE == MODE_GENERAL, "two-wave D = 256 backward: plain, causal, key padding, vector mask / bias");
     using E = ET<Tag>;
     using vec8 = typename E::vec8;
     const FwdParams& p = bp.f;
     constexpr int D = 256, KS = 16, DB = 8, BM = 128, KU = 32;
     constexpr bool KP = MODE == MODE_KEYPAD;   // a boolean mask over (batch, head, key), with or without the causal flag
-    const bool causal = MODE == MODE_CAUSAL || (KP && p.causal != 0);
+    constexpr bool GEN = MODE == MODE_GENERAL;
+    constexpr int NV = GEN ? 3 : B256_RING;    // V ring slots
+    constexpr int NIMG = GEN ? 3 : 0;          // image requests of an A wave per unit
+    const bool causal = MODE == MODE_CAUSAL || ((KP || GEN) && p.causal != 0);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsK = smem;                                   // [RING][UNIT]
-    char* const ldsV = smem + B256_RING * B256_UNIT;           // [RING][UNIT]
-    char* const ldsP = smem + 2 * B256_RING * B256_UNIT;       // [2][4 row blocks][2 KiB]
-    uint64_t* const ldsKP = reinterpret_cast<uint64_t*>(smem + 2 * B256_RING * B256_UNIT + 2 * 4 * 2048);   // [kDq256KpTiles]
+    char* const ldsV = smem + B256_RING * B256_UNIT;           // [NV][UNIT]
+    char* const ldsP = smem + (B256_RING + NV) * B256_UNIT;    // [2][4 row blocks][2 KiB]
+    uint64_t* const ldsKP = reinterpret_cast<uint64_t*>(ldsP + 2 * 4 * 2048);   // [kDq256KpTiles] (key-padding mode)
+    char* const ldsI = ldsP + 2 * 4 * 2048;                    // [4 A waves][2][B256_IMG] (MODE_GENERAL)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -383,10 +395,56 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
     const u32x4 vrw = make_rsrc_words(p.v + (b * p.vs[0] + (h / p.kvg) * p.vs[1]) * 2, p.vbytes);
     const uint32_t ldsK_w = lds_addr(ldsK) + wave * 1024, ldsV_w = lds_addr(ldsV) + wave * 1024;
     const int past = (p.Sk + KU - 1) / KU + 8;
+    // ---- MODE_GENERAL: this A wave's images (layout and reads as in fasn_fwd_ws256.h)
+    u32x4 brw = {0u, 0u, 0u, 0u}, mrw = {0u, 0u, 0u, 0u};
+    unsigned bvo[2] = {0u, 0u}, mvo = 0u;
+    if (GEN) {
+        brw = make_rsrc_words(p.bias ? p.bias + (b * p.bs[0] + h * p.bs[1]) * 2 : p.q, p.bias ? p.bias_bytes : 0u);
+        mrw = make_rsrc_words(p.mask ? reinterpret_cast<const char*>(p.mask) + (b * p.ms[0] + h * p.ms[1]) : p.q, p.mask ? p.mask_bytes : 0u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = i * 64 + lane, r = sl >> 2, c = (sl & 3) ^ swz_f<32>(r);
+            bvo[i] = (unsigned)(((qw0 + r) * (int)p.bs[2] + c * 8) * 2);
+        }
+        mvo = (unsigned)((qw0 + (lane >> 1)) * (int)p.ms[2] + (lane & 1) * 16);
+    }
+    char* const img = ldsI + rbw * (2 * B256_IMG);
+    const uint32_t img_a = lds_addr(img);
+    auto img_dma = [&](int u, int slot) {   // 3 requests; units past the last key are out of the descriptors' range: zeros, no traffic
+        const int uu = u < nu ? u : past;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16(brw, __builtin_amdgcn_readfirstlane(img_a + slot * B256_IMG + i * 1024), bvo[i], (uint32_t)uu * (uint32_t)(KU * 2));
+        lds_dma16(mrw, __builtin_amdgcn_readfirstlane(img_a + slot * B256_IMG + 2048), mvo, (uint32_t)uu * (uint32_t)KU);
+    };
+    const uint32_t nomask = (GEN && p.mask == nullptr) ? 0x01010101u : 0u;
+    const char* const img_rd_b = img + l31 * 64 + hi * 8;
+    const char* const img_rd_m = img + 2048 + l31 * 32 + hi * 4;
+    const int img_swz = swz_f<32>(l31);
+    u32x2 braw[4] = {};
+    uint32_t mraw[4] = {};
+    auto img_read = [&](int slot) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            braw[g] = *LDS_PTR(const u32x2, img_rd_b + slot * B256_IMG + ((g ^ img_swz) << 4));
+            mraw[g] = *LDS_PTR(const uint32_t, img_rd_m + slot * B256_IMG + 8 * g);
+        }
+    };
+    // iteration u of the loops below calls requests(u + 2): K unit u + 2 (and V unit u + 2; MODE_GENERAL: V unit u + 1, with three slots, in front of
+    // the image of unit u + 2 and the K unit - vmcnt counts in order, see fasn_fwd_ws256.h)
     auto requests = [&](int u) {
         const int uu = u < nu ? u : past;
-        dk_.dma(krw, ldsK_w + (u & 3) * B256_UNIT, uu * KU, p.ks[2]);
-        dv_.dma(vrw, ldsV_w + (u & 3) * B256_UNIT, uu * KU, p.vs[2]);
+        if constexpr (GEN) {   // (the image and K requests follow in late_requests: wave A issues them once the unit's image is in its start values)
+            const int uv = u - 1 < nu ? u - 1 : past;
+            dv_.dma(vrw, ldsV_w + ((u - 1) % 3) * B256_UNIT, uv * KU, p.vs[2]);
+        } else {
+            dk_.dma(krw, ldsK_w + (u & 3) * B256_UNIT, uu * KU, p.ks[2]);
+            dv_.dma(vrw, ldsV_w + (u & 3) * B256_UNIT, uu * KU, p.vs[2]);
+        }
+    };
+
+    auto late_requests = [&](int u) {   // MODE_GENERAL: [A: the image of unit u into the slot whose image was just consumed] [K unit u]
+        if (role == 0) img_dma(u, u & 1);
+        dk_.dma(krw, ldsK_w + (u & 3) * B256_UNIT, (u < nu ? u : past) * KU, p.ks[2]);
     };
 
     // this wave's operand fragment (B operand: col = q row, k = 8 features): Q' for A, dO for B; and its row statistic
@@ -409,8 +467,18 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
         }
     }
     if (nu > 0) {
-        requests(0);
-        requests(1);
+        if constexpr (GEN) {   // K units 0 and 1, V unit 0, the images of units 0 and 1
+            dk_.dma(krw, ldsK_w, 0, p.ks[2]);
+            dk_.dma(krw, ldsK_w + B256_UNIT, (1 < nu ? 1 : past) * KU, p.ks[2]);
+            dv_.dma(vrw, ldsV_w, 0, p.vs[2]);
+            if (role == 0) {
+                img_dma(0, 0);
+                img_dma(1, 1);
+            }
+        } else {
+            requests(0);
+            requests(1);
+        }
     }
     if (KP) kp_build_words(ldsKP, p.mask ? p.mask + (b * p.ms[0] + h * p.ms[1]) : nullptr, p.Sk, (p.Sk + 63) / 64, tid, 512);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -476,6 +544,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
         asm volatile("" : "+v"(ol));   // registers across the loop next to 192 persistent ones (a spilled address comes back through scratch with a vmcnt wait)
         char* ps = pslot + (u & 1) * 8192;
         if (skip) {
+            if constexpr (GEN) late_requests(u + 2);
             *LDS_PTR(u32x4, ps) = u32x4{0u, 0u, 0u, 0u};
             *LDS_PTR(u32x4, ps + 1024) = u32x4{0u, 0u, 0u, 0u};
             return;
@@ -484,6 +553,17 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = stat;   // (a 16-register splat kept for the whole kernel would not fit next to 192)
+        if constexpr (GEN) {   // + bias*log2e, -inf where the mask byte is clear: the unit's image goes straight into the start values, then its slot is asked for again
+            img_read(u & 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t w = braw[r >> 2][(r & 3) >> 1];
+                const float bv = __builtin_fmaf(E::to_f32((uint16_t)((r & 1) ? (w >> 16) : (w & 0xffffu))), kLog2e, stat);
+                sacc[r] = (((mraw[r >> 2] | nomask) >> (8 * (r & 3))) & 0xffu) ? bv : -INFINITY;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is in registers before its slot is asked for again
+            late_requests(u + 2);
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const vec8 kf = lds_read_rowfrag<E, D>(tK, ol & 31, s, ol >> 5);
@@ -518,7 +598,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
         asm volatile("" : "+v"(ol));   // registers across the loop next to 192 persistent ones (a spilled address comes back through scratch with a vmcnt wait)
         if (skip) return;
         const char* tK = ldsK + (u & 3) * B256_UNIT;
-        const char* tV = ldsV + (u & 3) * B256_UNIT;
+        const char* tV = ldsV + (GEN ? u % 3 : u & 3) * B256_UNIT;
         const char* ps = pslot + (u & 1) * 8192;
         const u32x4 w0 = *LDS_PTR(const u32x4, ps), w1 = *LDS_PTR(const u32x4, ps + 1024);
         f32x16 pacc;
@@ -549,16 +629,21 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
                 acc[d] = E::mfma(ktf, dsf[t2], acc[d]);
             }
     };
-    auto close = [&]() {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    auto close = [&](auto ROLE_) {
+        // what may stay in flight: this iteration's requests (MODE_GENERAL: 4 + the A wave's 3 image pieces)
+        if constexpr (GEN && decltype(ROLE_)::value == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NIMG) : "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __syncthreads();
     };
+    using RoleA = std::integral_constant<int, 0>;
+    using RoleB = std::integral_constant<int, 1>;
     if (role == 0) {
         if (nu > 0)
             for (int u = 0; u <= nu; ++u) {
                 requests(u + 2);
                 if (u < nu) unit_a(u);
-                close();
+                else if constexpr (GEN) late_requests(u + 2);
+                close(RoleA{});
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -570,15 +655,17 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
         if (nu > 0)
             for (int u = 0; u <= nu; ++u) {
                 requests(u + 2);
+                if constexpr (GEN) late_requests(u + 2);
                 if (u > 0) unit_b(u - 1, acc);
-                close();
+                close(RoleB{});
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (row_ok) {
-            char* rp = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1] + (int64_t)row * bp.dqs[2]) * 2;
+            const int lane_e = GEN ? fresh_lane_id() : lane;   // (MODE_GENERAL: the row address from a fresh lane id - the one value that was parked in scratch across the loop)
+            char* rp = bp.dq + (b * bp.dqs[0] + h * bp.dqs[1] + (int64_t)(qw0 + (lane_e & 31)) * bp.dqs[2]) * 2;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
-                store_block_wide<E>(rp + d * 64, acc[d], bp.scale, hi);   // 16-byte stores (round 5, fasn_common.h)
+                store_block_wide<E>(rp + d * 64, acc[d], bp.scale, lane_e >> 5);   // 16-byte stores (round 5, fasn_common.h)
         }
     }
 }
