@@ -5,6 +5,9 @@
 // kernels (round 6), operands whose rows do not move as vectors the element-load kernels.
 #include "fasn_bwd_launch.h"
 #include "fasn_bwd_ws256.h"
+#ifndef FASN_D256_VEC_DH
+#define FASN_D256_VEC_DH 2   // feature halves of the one-wave vector dK/dV kernels (1: whole rows, 94 - 124 spilled registers; A/B in LABNOTES)
+#endif
 #ifndef FASN_D256_GEN_WS
 #define FASN_D256_GEN_WS 1
 #endif
@@ -61,7 +64,7 @@ static int go(const BwdParams& p, int mode, hipStream_t s) {
     if (p.f.drop_thr) {   // dropout (round 6): ONE vector instantiation for every mode whose mask / bias rows move as vectors - no operand at all included
         const int md = mode == MODE_KEYPAD ? p.f.keypad_fallback : mode;
         if (md == MODE_GENERAL_SLOW) return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL_SLOW, 1, 1, 1, 0, 2>(p, s);
-        return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 1, 0, 2>(p, s);
+        return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 1, 0, FASN_D256_VEC_DH>(p, s);
     }
     if (!(FASN_BWD_VARIANT & 1)) {   // (developer library: bwd_variant bit 0 = the round-3 feature-half kernels, for A/B)
         if (mode == MODE_PLAIN) return launch_ws256<Tag, MODE_PLAIN>(p, s);      // (grouped K/V included since round 5)
@@ -91,9 +94,9 @@ static int go(const BwdParams& p, int mode, hipStream_t s) {
                 FASN_LAUNCH(kern, dim3((unsigned)(q.nblk * nbh)), dim3(512), smem, s, q);
                 BwdParams r = p;
                 r.skip |= 2 | 4;   // dQ and delta are launched
-                return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 0, 0, 2>(r, s);
+                return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 0, 0, FASN_D256_VEC_DH>(r, s);
             }
-            return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 0, 0, 2>(p, s);
+            return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL, 1, 1, 0, 0, FASN_D256_VEC_DH>(p, s);
         default: return launch_bwd_one<Tag, 256, 1, 1, MODE_GENERAL_SLOW, 1, 1, 0, 0, 2>(p, s);
     }
 }

@@ -55,6 +55,6 @@ for dtn in dts:
             fl = 4.0 * B * H * S * S * D * (0.5 if kw.get("is_causal") else 1.0)
             try:
                 tf, tb = timeit(fwd), timeit(fwdbwd)
-                print(f'{dtn} D={D:3d} {name:22s} fwd "ms_per_step": {tf:8.4f} ({fl / tf * 1e-9:7.1f} TF)   fwd+bwd "ms_per_step": {tb:8.4f} ({3.5 * fl / tb * 1e-9:7.1f} TF)', flush=True)
+                print(f'{dtn} D={D:3d} {name:22s} fwd "ms_per_step": {tf:.4f} ({fl / tf * 1e-9:7.1f} TF)   fwd+bwd "ms_per_step": {tb:.4f} ({3.5 * fl / tb * 1e-9:7.1f} TF)', flush=True)
             except Exception as e:   # a mode the front end refuses for this dtype / head dim
                 print(f'{dtn} D={D:3d} {name:22s} -- {type(e).__name__}: {str(e)[:90]}', flush=True)
