@@ -384,7 +384,6 @@ int fasn_fwd_path(const fasn_fwd_args* args) {
     if (rc) return rc;
     if (l.dtype == FASN_DTYPE_F32) return FASN_PATH_FP32;
     int mode = l.mode;
-    if (p.drop_thr && mode == MODE_BIAS_KEYPAD) mode = p.keypad_fallback;   // (no dropout instantiation of its own)
     if (l.D > 128 && (p.drop_thr || mode == MODE_BIAS_KEYPAD)) {            // D = 256: dropout and bias + key padding through the general modes (launch_fwd_d256)
         if (mode == MODE_KEYPAD || mode == MODE_BIAS_KEYPAD) mode = p.keypad_fallback;
         if (p.drop_thr) return mode == MODE_GENERAL_SLOW ? FASN_PATH_ELEMENT : FASN_PATH_VECTOR;

@@ -117,6 +117,9 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
     return launch_rc();
 }
 
+#ifndef FASN_DROP_BK
+#define FASN_DROP_BK 1
+#endif
 template <typename Tag, int D, int QB, int KB, int OCC_Q, int OCC_K, int WS = 0>
 int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
     if (p.f.drop_thr) {   // dropout: separate instantiations (the keep-bit hash costs registers the p = 0 kernels keep)
@@ -125,6 +128,11 @@ int launch_bwd_mode(const BwdParams& p, int mode, hipStream_t s) {
         if (mode == MODE_BIAS_KEYPAD) {
             if constexpr (WS != 0) {
                 if (p.f.kvg == 1) return launch_bwd_one<Tag, D, QB, KB, MODE_BIAS_KEYPAD, 1, 1, 1, WS>(p, s);
+            }
+            // head dims 32 / 64 (round 6): the mode's own one-wave instantiations with dropout at the vector modes' tuning point (two waves per SIMD,
+            // D = 32: one block per wave) instead of the dense-mask general mode
+            if constexpr (D <= 64) {
+                if (FASN_DROP_BK) return launch_bwd_one<Tag, D, (D == 32 ? 1 : QB), (D == 32 ? 1 : KB), MODE_BIAS_KEYPAD, 2, 2, 1>(p, s);
             }
             mode = p.f.keypad_fallback;
         }

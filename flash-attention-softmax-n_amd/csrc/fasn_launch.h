@@ -131,12 +131,18 @@ int launch_fwd_cfg(const FwdParams& p, int mode, hipStream_t s) {
 // kernels run at the plain kernels' tuning points, seeded accumulators and packed row sums (SEED = 2) included: 64 rows per wave at D = 64 no
 // longer spill (244 registers; the round-5 hash needed 37 - 67 more), three waves per SIMD fit in 144.
 // QB / OCC: the tuning point of the plain kernel for this launch (fasn_fwd_d*.hip decides by the size of the grid).
+#ifndef FASN_DROP_BK
+#define FASN_DROP_BK 1
+#endif
 template <typename Tag, int D, int QB, int OCC>
 int launch_fwd_drop(const FwdParams& p, int mode, hipStream_t s) {
     if (mode == MODE_BIAS_KEYPAD) {
         // vector bias + key-padding mask (ALiBi on a padded batch) with dropout: the visibility-word kernel at D = 128 (round 4), elsewhere
         // the dense-mask general mode of the same mask
         if constexpr (D == 128) return launch_fwd_one<Tag, D, 1, MODE_BIAS_KEYPAD, 2, 8, 2, 2, 1>(p, s);
+        // head dims 32 / 64 (round 6, FASN_DROP_BK): the same mode at the vector dropout kernels' tuning point (154 / 174 registers) instead of the
+        // dense-mask general mode of the same mask (a mask image per tile next to the bias image)
+        else if (FASN_DROP_BK) return launch_fwd_one<Tag, D, (D == 32 ? 2 : 1), MODE_BIAS_KEYPAD, 2, 4, (D == 32 ? 2 : 0), 2, 1>(p, s);
         else mode = p.keypad_fallback;
     }
     if (mode == MODE_PLAIN) {

@@ -1,7 +1,7 @@
 """Tuning-point audit: every (head dim, dtype, mode) through flash_attention_n at one mid-size shape, forward and forward + backward, as
 algorithmic TFLOP/s (4 B H L S D forward, 2.5 x that for the backward's five GEMM-equivalents; causal counts half). A mode far below its
 neighbours of the same head dim runs a kernel at the wrong tuning point (waves per SIMD, rows per wave, ring) - that is what this looks for.
-  python tools/audit_modes.py [S=2048] [dims=32,64,128,256] [dtypes=bf16,f16,f32]
+  python tools/audit_modes.py [S=2048] [dims=32,64,128,256] [dtypes=bf16,f16,f32] [only modes whose name contains this]
 Lines also carry "ms_per_step" so that tools/ab_libs.sh can alternate libraries."""
 import sys, torch
 sys.path.insert(0, '/root/repo')
@@ -12,6 +12,7 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 dims = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "32,64,128,256").split(",")]
 dts = (sys.argv[3] if len(sys.argv) > 3 else "bf16,f32").split(",")
 DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+only = sys.argv[4] if len(sys.argv) > 4 else ""
 
 def timeit(fn, budget_ms=150.0):
     for _ in range(2): fn()
@@ -44,6 +45,8 @@ for dtn in dts:
                  ("gqa4+causal", dict(_gqa=True, is_causal=True))]
         if dtn != "f32": modes.append(("f32 bias+keypad", dict(attn_bias=bias32, attn_mask=kp)))
         for name, kw in modes:
+            if only not in name:
+                continue
             kw = dict(kw)
             kk, vv = (kg, vg) if kw.pop("_gqa", False) else (k, v)
             def fwd():
