@@ -19,6 +19,27 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 #ifndef FASN_D32_VEC_RING
 #define FASN_D32_VEC_RING 2
 #endif
+    // causal next to a mask / bias (unequal workgroups) on a grid of less than FASN_D32_VEC_CAUSAL_BLOCKS 256-row blocks: 128-row workgroups, three per CU
+    // (111 - 140 registers) - a one-round launch of 256-row blocks takes as long as the call without the causal flag
+#ifndef FASN_D32_VEC_QB1_ALL
+#define FASN_D32_VEC_QB1_ALL 0
+#endif
+#ifndef FASN_D32_VEC_CAUSAL_BLOCKS
+#define FASN_D32_VEC_CAUSAL_BLOCKS (1L << 40)   // (every causal launch: -20 .. -28 % up to one round of 256-row blocks, still -3 % at 2048 blocks; profiles/r06_causal_next_to_a_bias_forward_rule_ab.log)
+#endif
+    // The same 128-row workgroups without the causal flag (same log): bias + dense mask -6 .. -8 % at every size; bias + key padding (length pairs: half
+    // the workgroups) -26 / -15 % below 1024 blocks, +3.5 % above; bias alone and mask alone: a tie - they keep 256 rows.
+    const long b256 = (long)((p.Sq + 255) / 256) * p.B * p.H;
+    const bool small_wg = FASN_D32_VEC_QB1_ALL || (p.causal && b256 < FASN_D32_VEC_CAUSAL_BLOCKS) || l.mode == MODE_GENERAL || (l.mode == MODE_BIAS_KEYPAD && b256 < 1024);
+    if (small_wg) {
+        switch (l.mode) {
+            case MODE_GENERAL: return launch_fwd_one<Tag, 32, 1, MODE_GENERAL, 3, 4, 2, 2>(p, s);
+            case MODE_GENERAL_B: return launch_fwd_one<Tag, 32, 1, MODE_GENERAL_B, 3, 4, 2, 2>(p, s);
+            case MODE_GENERAL_M: return launch_fwd_one<Tag, 32, 1, MODE_GENERAL_M, 3, 4, 2, 2>(p, s);
+            case MODE_BIAS_KEYPAD: return launch_fwd_one<Tag, 32, 1, MODE_BIAS_KEYPAD, 3, 4, 2, 2>(p, s);
+            default: break;
+        }
+    }
     switch (l.mode) {
         case MODE_GENERAL: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL, FASN_D32_VEC_OCC, 4, FASN_D32_VEC_RING, 2>(p, s);
         case MODE_GENERAL_B: return launch_fwd_one<Tag, 32, 2, MODE_GENERAL_B, FASN_D32_VEC_OCC, 4, FASN_D32_VEC_RING, 2>(p, s);

@@ -34,10 +34,15 @@ static int launch_gen(const FwdParams& p, const FwdLaunch& l, hipStream_t s) {
 #ifndef FASN_D64_BIAS_8WAVE
 #define FASN_D64_BIAS_8WAVE 1
 #endif
+#ifndef FASN_D64_BIAS_8WAVE_CAUSAL
+#define FASN_D64_BIAS_8WAVE_CAUSAL 2
+#endif
     const long blocks512 = (long)((p.Sq + 511) / 512) * p.B * p.H;
     // (a full round of one workgroup per CU; the bias + key-padding mode pairs its batch elements by length - half as many workgroups - and needs
     // two: at (8,16,1024,64), 256 blocks, the paired 8-wave launch left half of the CUs idle, 0.089 against 0.064 ms)
-    if (FASN_D64_BIAS_8WAVE && blocks512 >= (l.mode == MODE_BIAS_KEYPAD ? 512 : 256) && p.Sq >= 512) {
+    // (causal next to a mask / bias: the workgroups of a launch are unequal - a one-round launch of 512-row blocks takes as long as the same call without
+    // the causal flag, the heaviest block sets the time - so the 8-wave kernel needs twice as many blocks: (4,16,2048,64) causal + bias 0.090 -> 0.068 ms, at (4,16,4096,64), two rounds, the 8-wave kernel is 2 % ahead again; profiles/r06_causal_next_to_a_bias_forward_rule_ab.log)
+    if (FASN_D64_BIAS_8WAVE && blocks512 >= (l.mode == MODE_BIAS_KEYPAD ? 512 : 256) * (p.causal ? FASN_D64_BIAS_8WAVE_CAUSAL : 1) && p.Sq >= 512) {
         switch (l.mode) {
             case MODE_GENERAL: return launch_fwd_one<Tag, 64, 2, MODE_GENERAL, 2, 8, 2, 2>(p, s);
             case MODE_GENERAL_B: return launch_fwd_one<Tag, 64, 2, MODE_GENERAL_B, 2, 8, 2, 2>(p, s);
