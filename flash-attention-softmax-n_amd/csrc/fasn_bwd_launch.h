@@ -72,7 +72,8 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         constexpr auto kern = &fasn_bwd_dq_kernel<Tag, D, QB, MODE, OCC_Q, DROP, (D >= 128 ? FASN_DQ_SEED_D128 : D == 32 ? FASN_DQ_SEED_D32 : 3), BF32>;
         ensure_smem<kern>(smem);
         // causal: block r and block nblk-1-r in one workgroup (equal workgroups for the in-order dispatcher, see fasn_fwd_kernel.h)
-        p.f.pair = (MODE == MODE_CAUSAL && !DROP && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * OCC_Q)) ? 1 : 0;
+        constexpr bool VEC_PAIR = FASN_VEC_PAIR && D <= 128 && mode_is_vector(MODE) && !mode_has_keypad(MODE);   // (the vector modes of a causal call pair their blocks too, fasn_launch.h)
+        p.f.pair = ((MODE == MODE_CAUSAL || (VEC_PAIR && p.f.causal)) && !DROP && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * OCC_Q)) ? 1 : 0;
         FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
         p.f.pair = 0;
     }
@@ -110,7 +111,8 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         } else {
             constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 0, DH, BF32>;
             ensure_smem<kern>(smem);
-            p.f.pair = (MODE == MODE_CAUSAL && !DROP && DH == 1 && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * OCC_K)) ? 1 : 0;
+            constexpr bool VEC_PAIRK = FASN_VEC_PAIR && mode_is_vector(MODE) && !mode_has_keypad(MODE);
+            p.f.pair = ((MODE == MODE_CAUSAL || (VEC_PAIRK && p.f.causal)) && !DROP && DH == 1 && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * OCC_K)) ? 1 : 0;
             FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh * DH)), dim3(256), smem, s, p);
         }
     }

@@ -88,7 +88,10 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
     // chip's workgroup slots at least kPairRounds times; smaller launches keep single blocks, heaviest first
     int blocks = p.nqblk;
     p.pair = 0;
-    if (MODE == MODE_CAUSAL && VH == 1 && !DROP && p.nqblk > 1 && pair_wanted((long)p.nqblk * p.B * p.H, 256L * OCC)) {
+    // (round 6: also the vector mask / bias modes when the call is causal - ALiBi in a decoder: without pairs a launch of unequal workgroups handed out
+    // head by head ends on heavy blocks that started late; (4,16,2048,64) causal + bias ran at 0.84 of the non-causal time instead of ~0.55)
+    constexpr bool VEC_PAIR = FASN_VEC_PAIR && mode_is_vector(MODE) && !mode_has_keypad(MODE);
+    if ((MODE == MODE_CAUSAL || (VEC_PAIR && p.causal)) && VH == 1 && !DROP && p.nqblk > 1 && pair_wanted((long)p.nqblk * p.B * p.H, 256L * OCC)) {
         p.pair = 1;
         blocks = (p.nqblk + 1) / 2;
     }
