@@ -11,7 +11,7 @@ static int launch_dkdv_pipe(BwdParams p, hipStream_t s) {
     p.nblk = (p.f.Sk + BN - 1) / BN;
     constexpr auto kern = &fasn_bwd_dkdv_pipe_kernel<Tag, MODE, DROP>;
     ensure_smem<kern>(smem);
-    p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * 2)) ? 1 : 0;
+    p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, wg_slots(2, 4, smem), true)) ? 1 : 0;
     FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
     return launch_rc();
 }
@@ -24,7 +24,7 @@ static int launch_dq_pipe(BwdParams p, hipStream_t s) {
     p.nblk = (p.f.Sq + BM - 1) / BM;
     constexpr auto kern = &fasn_bwd_dq_pipe_kernel<Tag, MODE, DROP>;
     ensure_smem<kern>(smem);
-    p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L * 2)) ? 1 : 0;
+    p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, wg_slots(2, 4, smem), true)) ? 1 : 0;
     FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
     return launch_rc();
 }
@@ -47,7 +47,7 @@ static int launch_dkdv_pipe2(BwdParams p, hipStream_t s) {
     p.nblk = (p.f.Sk + BN - 1) / BN;
     constexpr auto kern = &fasn_bwd_dkdv_pipe2_kernel<Tag, MODE, KB>;
     ensure_smem<kern>(smem);
-    p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, 256L)) ? 1 : 0;
+    p.f.pair = (MODE == MODE_CAUSAL && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, wg_slots(1, 4, smem), true)) ? 1 : 0;
     FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
     return launch_rc();
 }

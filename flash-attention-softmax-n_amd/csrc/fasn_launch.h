@@ -67,15 +67,35 @@ constexpr int fwd_smem(int D, int RING, int MODE, int NW, int QB, int BF32 = 0) 
 }
 
 // one instantiation of the forward kernel: NW waves x QB 32-row blocks per wave, staging scheme RING, accumulator seeding SEED
-constexpr int kPairRounds = 2;   // (measured: C3, 5.3 rounds of single blocks, 0.350 -> 0.335 ms paired; C5, 43 rounds, 2.45 -> 2.39; (4,32,8192,128) 2.19 -> 2.14)
+// Paired causal blocks (block r and block nblk-1-r in one workgroup: equal workgroups, see the kernels). Rounds 2 - 5: from two rounds of single blocks.
+// Round 6 (profiles/r06_causal_pairing_threshold_ab.log, (4,16,S,D) causal): the in-order dispatcher hands unequal workgroups out head by head, so the heavy
+// blocks of the last heads start late, and even a launch that is resident at once puts two heavy blocks on one CU - (4,16,2048,64) forward 0.064 -> 0.054 ms
+// paired at 1.33 rounds, (4,16,2048,32) -13 % at exactly one round, (4,16,2048,128) 0.117 -> 0.090 (its 96 KiB of LDS make 512 blocks TWO rounds: `slots`
+// now counts LDS). But pairs that do not fill the CUs evenly cost the forward more than they save below two rounds ((4,16,1536,64): 384 pairs on 256 CUs,
+// +7 % plain, +21 % with a bias), while dQ / dK/dV gained in every case measured from 1.25 rounds on. So: two rounds, or - forward - one round and a multiple
+// of 256 pairs, or - backward - 1.25 rounds.
+constexpr long wg_slots(int occ_waves_per_simd, int nw, int smem) {   // workgroups the chip holds at once
+    const long by_regs = occ_waves_per_simd * 4 / nw < 1 ? 1 : occ_waves_per_simd * 4 / nw;
+    const long by_lds = smem > 0 ? 163840 / smem : by_regs;
+    return 256L * (by_regs < by_lds ? by_regs : (by_lds < 1 ? 1 : by_lds));
+}
+#ifndef FASN_PAIR_RULE
+#define FASN_PAIR_RULE 6   // 5: the rule of rounds 2 - 5 (two rounds of single blocks; slots by registers only)
+#endif
+inline bool pair_rule(long blocks, long slots, bool backward) {
+    if (blocks >= 2 * slots) return true;
+    if (FASN_PAIR_RULE == 5) return false;
+    if (backward) return 4 * blocks >= 5 * slots;
+    return blocks >= slots && blocks % 512 == 0;
+}
 #ifdef FASN_DEV_VARIANTS
 extern int g_kprot;       // developer library: 0 = no rotated second pass of a length pair (A/B)
 extern int* g_xq;         // developer experiment: item counters of the dynamic deal across XCDs (zeroed here before every launch)
 extern int g_xq_extra;
 extern int g_pair_mode;   // developer library: -1 = shipped rule, 0 = never pair, 1 = always pair (tools/fasn_harness, env FASN_PAIR)
-inline bool pair_wanted(long blocks, long slots) { return g_pair_mode < 0 ? blocks >= kPairRounds * slots : g_pair_mode != 0; }
+inline bool pair_wanted(long blocks, long slots, bool backward = false) { return g_pair_mode < 0 ? pair_rule(blocks, slots, backward) : g_pair_mode != 0; }
 #else
-inline bool pair_wanted(long blocks, long slots) { return blocks >= kPairRounds * slots; }
+inline bool pair_wanted(long blocks, long slots, bool backward = false) { return pair_rule(blocks, slots, backward); }
 #endif
 template <typename Tag, int D, int QB, int MODE, int OCC, int NW = 4, int RING = 0, int SEED = 0, int DROP = 0, int VH = 1, int FOLD = 0, int BF32 = 0>
 int launch_fwd_one(FwdParams p, hipStream_t s) {
@@ -91,7 +111,7 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
     // (round 6: also the vector mask / bias modes when the call is causal - ALiBi in a decoder: without pairs a launch of unequal workgroups handed out
     // head by head ends on heavy blocks that started late; (4,16,2048,64) causal + bias ran at 0.84 of the non-causal time instead of ~0.55)
     constexpr bool VEC_PAIR = FASN_VEC_PAIR && mode_is_vector(MODE) && !mode_has_keypad(MODE);
-    if ((MODE == MODE_CAUSAL || (VEC_PAIR && p.causal)) && VH == 1 && !DROP && p.nqblk > 1 && pair_wanted((long)p.nqblk * p.B * p.H, 256L * OCC)) {
+    if ((MODE == MODE_CAUSAL || (VEC_PAIR && p.causal)) && VH == 1 && !DROP && p.nqblk > 1 && pair_wanted((long)p.nqblk * p.B * p.H, wg_slots(OCC, NW, smem))) {
         p.pair = 1;
         blocks = (p.nqblk + 1) / 2;
     }
