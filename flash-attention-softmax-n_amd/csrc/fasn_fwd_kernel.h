@@ -35,6 +35,9 @@
 #ifndef FASN_VEC_PAIR
 #define FASN_VEC_PAIR 1
 #endif
+#ifndef FASN_DROP_PAIR
+#define FASN_DROP_PAIR 1   // paired blocks in the causal dropout forward too (round 6)
+#endif
 namespace fasn {
 
 // MODE_GENERAL: mask and/or bias through 4-key vector (buffer) loads - needs key stride 1 and aligned rows (bias_vec /
@@ -290,7 +293,7 @@ __global__ void __launch_bounds__(NW * 64, OCC) fasn_fwd_kernel(const FwdParams 
     // a ballot turns the 64 bytes into a wave-uniform bit word; tiles with all keys visible run as plain tiles, tiles with none
     // are skipped, only the boundary tiles start their hidden scores at -inf. Key-padded batches cost what unpadded ones do.
     constexpr bool KP = mode_has_keypad(MODE);
-    constexpr bool PAIRABLE = (MODE == MODE_CAUSAL || (FASN_VEC_PAIR && mode_is_vector(MODE) && !mode_has_keypad(MODE))) && !SPLIT && VH == 1 && !DROP;   // (round 6: also the vector mask / bias modes under the causal flag)
+    constexpr bool PAIRABLE = (MODE == MODE_CAUSAL || (FASN_VEC_PAIR && mode_is_vector(MODE) && !mode_has_keypad(MODE))) && !SPLIT && VH == 1 && (!DROP || (FASN_DROP_PAIR && MODE == MODE_CAUSAL));   // (round 6: also the vector mask / bias modes under the causal flag)
     constexpr bool KPAIR = KP && VBIAS && !SPLIT && VH == 1 && !DROP;   // length-paired batch elements (see below)
     int bh2 = -1;   // KPAIR: the (b,h) of the second pass
     int kp_lead = 0;   // KPAIR: tile steps by which this workgroup starts its second pass before the group's last one (kpair_plan)

@@ -111,7 +111,7 @@ int launch_fwd_one(FwdParams p, hipStream_t s) {
     // (round 6: also the vector mask / bias modes when the call is causal - ALiBi in a decoder: without pairs a launch of unequal workgroups handed out
     // head by head ends on heavy blocks that started late; (4,16,2048,64) causal + bias ran at 0.84 of the non-causal time instead of ~0.55)
     constexpr bool VEC_PAIR = FASN_VEC_PAIR && mode_is_vector(MODE) && !mode_has_keypad(MODE);
-    if ((MODE == MODE_CAUSAL || (VEC_PAIR && p.causal)) && VH == 1 && !DROP && p.nqblk > 1 && pair_wanted((long)p.nqblk * p.B * p.H, wg_slots(OCC, NW, smem))) {
+    if ((MODE == MODE_CAUSAL || (VEC_PAIR && p.causal)) && VH == 1 && (!DROP || (FASN_DROP_PAIR && MODE == MODE_CAUSAL)) && p.nqblk > 1 && pair_wanted((long)p.nqblk * p.B * p.H, wg_slots(OCC, NW, smem))) {
         p.pair = 1;
         blocks = (p.nqblk + 1) / 2;
     }
