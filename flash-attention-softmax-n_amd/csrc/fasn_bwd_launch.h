@@ -73,7 +73,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
         ensure_smem<kern>(smem);
         // causal: block r and block nblk-1-r in one workgroup (equal workgroups for the in-order dispatcher, see fasn_fwd_kernel.h)
         constexpr bool VEC_PAIR = FASN_VEC_PAIR && D <= 128 && mode_is_vector(MODE) && !mode_has_keypad(MODE);   // (the vector modes of a causal call pair their blocks too, fasn_launch.h)
-        p.f.pair = ((MODE == MODE_CAUSAL || (VEC_PAIR && p.f.causal)) && !DROP && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, wg_slots(OCC_Q, 4, smem), true)) ? 1 : 0;
+        p.f.pair = ((MODE == MODE_CAUSAL || (VEC_PAIR && p.f.causal)) && (!DROP || (FASN_DROP_PAIR && MODE == MODE_CAUSAL)) && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, wg_slots(OCC_Q, 4, smem), true)) ? 1 : 0;
         FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh)), dim3(256), smem, s, p);
         p.f.pair = 0;
     }
@@ -112,7 +112,7 @@ int launch_bwd_one(BwdParams p, hipStream_t s) {
             constexpr auto kern = &fasn_bwd_dkdv_kernel<Tag, D, KB, MODE, OCC_K, DROP, 0, DH, BF32>;
             ensure_smem<kern>(smem);
             constexpr bool VEC_PAIRK = FASN_VEC_PAIR && mode_is_vector(MODE) && !mode_has_keypad(MODE);
-            p.f.pair = ((MODE == MODE_CAUSAL || (VEC_PAIRK && p.f.causal)) && !DROP && DH == 1 && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, wg_slots(OCC_K, 4, smem), true)) ? 1 : 0;
+            p.f.pair = ((MODE == MODE_CAUSAL || (VEC_PAIRK && p.f.causal)) && (!DROP || (FASN_DROP_PAIR && MODE == MODE_CAUSAL)) && DH == 1 && p.nblk > 1 && pair_wanted((long)p.nblk * nbh, wg_slots(OCC_K, 4, smem), true)) ? 1 : 0;
             FASN_LAUNCH(kern, dim3((unsigned)((p.f.pair ? (p.nblk + 1) / 2 : p.nblk) * nbh * DH)), dim3(256), smem, s, p);
         }
     }
