@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(512, 2) FASN_WS_ATTR fasn_bwd_dkdv_ws_kernel(c
         kblk = rest % bp.nblk;
         bhk = bb * Hkv + (rest / bp.nblk) * 8 + xcd;
     } else {
-        block_to_work(blockIdx.x, p.B * Hkv, bp.nblk, bhk, kblk);
+        const bool causal0 = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);   // (key block 0 is the heaviest: ascending order = heaviest first)
+        block_to_work_grouped(blockIdx.x, p.B * Hkv, bp.nblk, (FASN_CAUSAL_GROUPS && causal0) ? causal_head_group(p.B * Hkv, p.Sq * kvg, D) : 1, bhk, kblk);
     }
     const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
     const int b = bhk / Hkv, hk = bhk % Hkv;

@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws_kernel(const BwdParams 
         qi0 = rest % bp.nblk;
         bh0 = bb * p.H + (rest / bp.nblk) * 8 + xcd;
     } else {
-        block_to_work(blockIdx.x, p.B * p.H, bp.nblk, bh0, qi0);
+        const bool causal0 = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
+        block_to_work_grouped(blockIdx.x, p.B * p.H, bp.nblk, (FASN_CAUSAL_GROUPS && causal0) ? causal_head_group(p.B * p.H, p.Sk, D) : 1, bh0, qi0);
     }
     auto item = [&](const int bh, const int qi, auto SECOND_) __attribute__((always_inline)) {
     constexpr bool ROT = KPAIR && decltype(SECOND_)::value;   // second element of a length pair: rotated key walk (fasn_fwd_kernel.h, kpair_plan)

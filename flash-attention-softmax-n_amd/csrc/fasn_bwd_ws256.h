@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dkdv_ws256_kernel(const BwdPa
 
     const int G = GQA ? p.kvg : 1, HK = p.H / G;   // query heads per K/V head, K/V heads
     int bhk, kblk;
-    block_to_work((int)blockIdx.x, p.B * HK, bp.nblk, bhk, kblk);
+    block_to_work_grouped((int)blockIdx.x, p.B * HK, bp.nblk, (FASN_CAUSAL_GROUPS && causal) ? causal_head_group(p.B * HK, p.Sq * G, D) : 1, bhk, kblk);   // (causal: heads in groups, fasn_common.h)
     const int b = bhk / HK, hk = bhk % HK;
     const int h = hk * G;   // first query head of the group (the only one without GQA)
     const int kw0 = kblk * BN + kbw * 32;
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(512, 2) fasn_bwd_dq_ws256_kernel(const BwdPara
     const int rbw = wave & 3;
 
     int bh, qi;
-    block_to_work((int)blockIdx.x, p.B * p.H, bp.nblk, bh, qi);
+    block_to_work_grouped((int)blockIdx.x, p.B * p.H, bp.nblk, (FASN_CAUSAL_GROUPS && causal) ? causal_head_group(p.B * p.H, p.Sk, D) : 1, bh, qi);
     const int qblk = causal ? (bp.nblk - 1 - qi) : qi;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * BM;

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(512, 2) fasn_fwd_ws256_kernel(const FwdParams 
     const int rbw = wave & 3;
 
     int bh, qi;
-    block_to_work((int)blockIdx.x, p.B * p.H, p.nqblk, bh, qi);
+    block_to_work_grouped((int)blockIdx.x, p.B * p.H, p.nqblk, (FASN_CAUSAL_GROUPS && causal) ? causal_head_group(p.B * p.H, p.Sk, D) : 1, bh, qi);   // (causal: heads in groups, fasn_common.h)
     const int qblk = causal ? (p.nqblk - 1 - qi) : qi;   // heaviest blocks first
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qblk * BM;
