@@ -104,6 +104,26 @@ def test_causal_launches_with_a_mask_or_bias_pair_their_blocks(pkg, dev, L, S, k
             _check(got, want, dtype, f"causal {kind} D={D} L{L} S{S} [{b},{h}] {nm}")
 
 
+@pytest.mark.parametrize("D", [128, 256])
+@pytest.mark.parametrize("B,H,Hkv,L,S", [(2, 16, 16, 640, 640), (2, 16, 16, 384, 640), (4, 8, 8, 650, 648), (2, 32, 8, 512, 512), (1, 8, 8, 1100, 1100)])
+def test_causal_two_wave_kernels_hand_blocks_out_by_head_groups(pkg, dev, B, H, Hkv, L, S, D):
+    """Round 6: causal launches of the two-wave kernels (D = 128 dQ / dK/dV, D = 256 forward / dQ / dK/dV) take the heads of an XCD in groups and hand a
+    group's blocks out block index by block index (csrc/fasn_common.h: block_to_work_grouped). Batch x heads a multiple of 8 (16, 32), groups of 2 / 4,
+    odd block counts, L != S, grouped K/V: EVERY (batch, head) of forward and gradients against the oracle - a block mapped twice or not at all shows."""
+    dtype = torch.bfloat16
+    q = _rand((B, H, L, D), dtype, dev, 21).requires_grad_()
+    k, v = (_rand((B, Hkv, S, D), dtype, dev, s_).requires_grad_() for s_ in (22, 23))
+    do = _rand((B, H, L, D), dtype, dev, 24, std=1.0)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, is_causal=True)
+    out.backward(do)
+    G = H // Hkv
+    kx, vx = (t.detach().repeat_interleave(G, dim=1) for t in (k, v))
+    o, dq, dkx, dvx = _oracle_fwd_bwd(q, kx, vx, do, softmax_n_param=1.0, is_causal=True)
+    dk, dv = (t.view(B, Hkv, G, S, D).sum(2) for t in (dkx, dvx))
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"causal D={D} ({B},{H}/{Hkv},{L},{S}) {nm}")
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_folded_causal_kernel_agrees_with_the_32_row_kernel(pkg, dev, seed):
     """Causal launches of 2048+ 256-row blocks take the folded two-phase forward kernel (round 5, FOLD in csrc/fasn_fwd_kernel.h: rows folded
