@@ -104,6 +104,42 @@ def test_causal_launches_with_a_mask_or_bias_pair_their_blocks(pkg, dev, L, S, k
             _check(got, want, dtype, f"causal {kind} D={D} L{L} S{S} [{b},{h}] {nm}")
 
 
+@pytest.mark.parametrize("D", [32, 64])
+@pytest.mark.parametrize("kind", ["bias_hls", "bias_b1ls", "dense", "plain", "dropout"])
+def test_paired_causal_launches_cover_every_block_once(pkg, dev, kind, D):
+    """(4,32,1024,D) causal: 1024 blocks of 128 rows = two rounds - forward, dQ and dK/dV pair their blocks in every mode (plain, dropout, batch-broadcast
+    bias = the per-XCD (head, block pair, batch) order, per-batch bias, dense mask). EVERY (batch, head) of forward and gradients against the oracle:
+    a block pair mapped twice or not at all shows."""
+    dtype = torch.bfloat16
+    B, H, L, S = 4, 32, 1024, 1024
+    q = _rand((B, H, L, D), dtype, dev, 31).requires_grad_()
+    k, v = (_rand((B, H, S, D), dtype, dev, s_).requires_grad_() for s_ in (32, 33))
+    do = _rand((B, H, L, D), dtype, dev, 34, std=1.0)
+    gen = torch.Generator().manual_seed(6)
+    kw = dict(softmax_n_param=1.0, is_causal=True)
+    if kind == "bias_hls":
+        kw["attn_bias"] = torch.randn(H, L, S, generator=gen).to(dtype).to(dev)
+    if kind == "bias_b1ls":
+        kw["attn_bias"] = torch.randn(B, 1, L, S, generator=gen).to(dtype).to(dev)
+    if kind == "dense":
+        m = torch.rand(B, 1, L, S, generator=gen) < 0.8
+        m[..., 0] = True
+        kw["attn_mask"] = m.to(dev)
+    p = 0.1 if kind == "dropout" else 0.0
+    torch.manual_seed(5)
+    out = pkg.flash_attention_n(q, k, v, dropout_p=p, **kw)
+    state = pkg.flash_attn.last_dropout_state() if p > 0 else None
+    out.backward(do)
+    okw = {a: (c.float() if a == "attn_bias" else c) for a, c in kw.items()}
+    if p > 0:
+        keep = pkg.dropout.keep_mask(state[0], state[1], B, H, L, S, p)
+        o, dq, dk, dv = _oracle_dropout(q, k, v, do, keep, pkg.dropout.effective_p(p), **okw)
+    else:
+        o, dq, dk, dv = _oracle_fwd_bwd(q, k, v, do, **okw)
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        _check(got, want, dtype, f"paired causal {kind} D={D} {nm}")
+
+
 @pytest.mark.parametrize("D", [128, 256])
 @pytest.mark.parametrize("B,H,Hkv,L,S", [(2, 16, 16, 640, 640), (2, 16, 16, 384, 640), (4, 8, 8, 650, 648), (2, 32, 8, 512, 512), (1, 8, 8, 1100, 1100)])
 def test_causal_two_wave_kernels_hand_blocks_out_by_head_groups(pkg, dev, B, H, Hkv, L, S, D):
