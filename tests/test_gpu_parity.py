@@ -104,7 +104,7 @@ def test_causal_launches_with_a_mask_or_bias_pair_their_blocks(pkg, dev, L, S, k
             _check(got, want, dtype, f"causal {kind} D={D} L{L} S{S} [{b},{h}] {nm}")
 
 
-@pytest.mark.parametrize("D", [32, 64])
+@pytest.mark.parametrize("D", [32, 64, 128])   # (128: the forward pairs - 512 blocks of 256 rows on 256 workgroup slots -, the two-wave backward groups its heads)
 @pytest.mark.parametrize("kind", ["bias_hls", "bias_b1ls", "dense", "plain", "dropout"])
 def test_paired_causal_launches_cover_every_block_once(pkg, dev, kind, D):
     """(4,32,1024,D) causal: 1024 blocks of 128 rows = two rounds - forward, dQ and dK/dV pair their blocks in every mode (plain, dropout, batch-broadcast
