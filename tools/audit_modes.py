@@ -3,7 +3,7 @@ algorithmic TFLOP/s (4 B H L S D forward, 2.5 x that for the backward's five GEM
 neighbours of the same head dim runs a kernel at the wrong tuning point (waves per SIMD, rows per wave, ring) - that is what this looks for.
   python tools/audit_modes.py [S=2048] [dims=32,64,128,256] [dtypes=bf16,f16,f32] [only modes whose name contains this]
 Lines also carry "ms_per_step" so that tools/ab_libs.sh can alternate libraries."""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, '/root/repo')
 import flash_attention_softmax_n_amd as pkg
 from flash_attention_softmax_n_amd import synth
@@ -29,6 +29,8 @@ for dtn in dts:
     dt = DT[dtn]
     for D in dims:
         B, H = (4, 16) if dtn != "f32" else (2, 8)
+        if os.environ.get("AUDIT_BH"):   # AUDIT_BH=8,32: another batch x heads
+            B, H = (int(x) for x in os.environ["AUDIT_BH"].split(","))
         q, k, v = (synth.counter_normal((B, H, S, D), s, dtype=dt, device=dev).requires_grad_(True) for s in (101, 102, 103))
         do = synth.counter_normal((B, H, S, D), 104, std=1.0, dtype=dt, device=dev)
         kg, vg = (synth.counter_normal((B, H // 4, S, D), s, dtype=dt, device=dev).requires_grad_(True) for s in (105, 106))
