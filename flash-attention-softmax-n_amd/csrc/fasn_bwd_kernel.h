@@ -202,7 +202,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dq_kernel(const BwdParams b
     const bool causal = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
     // paired causal launch (see fasn_fwd_kernel.h): query block nblk-1-r, then block r, so that every workgroup walks the same number of tiles
     constexpr bool PAIRABLE = (MODE == MODE_CAUSAL || (FASN_VEC_PAIR && D <= 128 && mode_is_vector(MODE) && !mode_has_keypad(MODE))) && (!DROP || (FASN_DROP_PAIR && MODE == MODE_CAUSAL));   // (round 6: also the vector modes under the causal flag, and the causal dropout kernels)
-    block_to_work(blockIdx.x, p.B * p.H, (PAIRABLE && p.pair) ? (bp.nblk + 1) / 2 : bp.nblk, bh, qi);
+    // (a causal launch that does not pair - small, or grouped K/V in the dK/dV kernel below - takes its heads in groups, blocks heaviest first across a group: fasn_common.h)
+    block_to_work_grouped(blockIdx.x, p.B * p.H, (PAIRABLE && p.pair) ? (bp.nblk + 1) / 2 : bp.nblk,
+                          (FASN_CAUSAL_GROUPS && causal && !(PAIRABLE && p.pair)) ? causal_head_group(p.B * p.H, p.Sk, D) : 1, bh, qi);
     const int npass = (PAIRABLE && p.pair && qi != bp.nblk - 1 - qi) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
     if (pass) __syncthreads();   // the first block's last tile has been read by every wave before the buffers are refilled
@@ -676,7 +678,9 @@ __global__ void __launch_bounds__(256, OCC) fasn_bwd_dkdv_kernel(const BwdParams
     const int d0 = DH > 1 ? (int)(blockIdx.x % DH) * DB : 0;   // first feature block of this workgroup
     // paired causal launch (see fasn_fwd_kernel.h): key block r (seen by the most query rows), then block nblk-1-r
     constexpr bool PAIRABLE = (MODE == MODE_CAUSAL || (FASN_VEC_PAIR && mode_is_vector(MODE) && !mode_has_keypad(MODE))) && (!DROP || (FASN_DROP_PAIR && MODE == MODE_CAUSAL)) && !GQA && DH == 1;
-    block_to_work(DH > 1 ? (int)(blockIdx.x / DH) : (int)blockIdx.x, p.B * Hkv, (PAIRABLE && p.pair) ? (bp.nblk + 1) / 2 : bp.nblk, bhk, kblk0);
+    const bool causal_l = (MODE == MODE_CAUSAL) || (MODE >= MODE_GENERAL && p.causal);
+    block_to_work_grouped(DH > 1 ? (int)(blockIdx.x / DH) : (int)blockIdx.x, p.B * Hkv, (PAIRABLE && p.pair) ? (bp.nblk + 1) / 2 : bp.nblk,
+                          (FASN_CAUSAL_GROUPS && causal_l && !(PAIRABLE && p.pair)) ? causal_head_group(p.B * Hkv, p.Sq * kvg, D) : 1, bhk, kblk0);
     const int npass = (PAIRABLE && p.pair && kblk0 != bp.nblk - 1 - kblk0) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
     if (pass) __syncthreads();   // the first block's last tile has been read by every wave before the buffers are refilled
