@@ -22,8 +22,8 @@ def _view(v, strides, ptr=DUMMY):
 
 
 def bwd_args(pkg, name):
-    """BwdArgs of BASELINE config `name` (contiguous [B,H,S,D] tensors); .fwd is what fasn_fwd gets"""
-    B, H, S, D, dt, n, causal, c4 = CONFIGS[name]
+    """BwdArgs of BASELINE config `name` (contiguous [B,H,S,D] tensors); .fwd is what fasn_fwd gets. `name` may also be a tuple of the CONFIGS form."""
+    B, H, S, D, dt, n, causal, c4 = CONFIGS[name] if isinstance(name, str) else name
     a = pkg._lib.BwdArgs()
     f = a.fwd
     dense = (H * S * D, S * D, D, 1)

@@ -200,6 +200,29 @@ def test_bwd_path_query(pkg):
     assert lib.fasn_bwd_path(None) == -1
 
 
+def test_causal_launches_pair_their_blocks_by_the_round_6_rule(pkg):
+    """csrc/fasn_launch.h: pair_rule / wg_slots, read off the grids of recorded plans (no GPU): two rounds of single blocks pair; the forward also from one round
+    when the pairs fill the 256 CUs evenly; dQ / dK/dV from 1.25 rounds; slots count LDS (the D = 128 forward holds one workgroup per CU)."""
+    from baseline_plans import bwd_args
+    L = pkg._lib
+
+    def grids(B, H, S, D, which):
+        a = bwd_args(pkg, (B, H, S, D, 1, 1.0, 1, False))
+        return [(n.split("<")[0], g) for n, g, *_ in L.launch_plan_described(a, which)]
+
+    # head dim 64, 64 heads: forward = 128-row blocks at three workgroups per CU (768 slots)
+    assert grids(4, 16, 2048, 64, L.FASN_PLAN_FWD) == [("fasn_fwd_kernel", 512)]      # 1024 blocks = 1.33 rounds, 512 pairs = two per CU: paired
+    assert grids(4, 16, 1536, 64, L.FASN_PLAN_FWD) == [("fasn_fwd_kernel", 768)]      # 768 blocks = one round, 384 pairs would be 1.5 per CU: single blocks
+    assert grids(4, 16, 1024, 64, L.FASN_PLAN_FWD) == [("fasn_fwd_kernel", 512)]      # 512 blocks < 768 slots: single blocks
+    # the pipelined backward (two workgroups per CU: 512 slots): 768 blocks = 1.5 rounds pair, 512 do not
+    assert [g for _, g in grids(4, 16, 1536, 64, L.FASN_PLAN_BWD)] == [384, 384]
+    assert [g for _, g in grids(4, 16, 1024, 64, L.FASN_PLAN_BWD)] == [512, 512]
+    # head dim 128: the 4-wave forward's 96 KiB of LDS admit one workgroup per CU - 512 blocks of 128 rows are two rounds: paired
+    assert grids(4, 16, 1024, 128, L.FASN_PLAN_FWD) == [("fasn_fwd_kernel", 256)]
+    # head dim 32 (256-row blocks, two workgroups per CU): 512 blocks = one round, 256 pairs = one per CU: paired
+    assert grids(4, 16, 2048, 32, L.FASN_PLAN_FWD) == [("fasn_fwd_kernel", 256)]
+
+
 def test_front_end_refuses_cpu_and_unsupported(pkg):
     q = torch.zeros(1, 1, 4, 32)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
