@@ -140,6 +140,70 @@ def test_paired_causal_launches_cover_every_block_once(pkg, dev, kind, D):
         _check(got, want, dtype, f"paired causal {kind} D={D} {nm}")
 
 
+def _torch_reference_on_device(q, k, v, do, n, causal, mask, bias):
+    """fp32 attention with softmax_n by torch operators ON THE GPU (gradients by autograd): a completeness check for large grids - was every block
+    of every head written, exactly once? - not the parity oracle (that is oracle/, on the CPU, in the tests around this one)."""
+    qf, kf, vf = (t.detach().float().requires_grad_() for t in (q, k, v))
+    G = qf.shape[1] // kf.shape[1]
+    kx, vx = (t.repeat_interleave(G, dim=1) if G > 1 else t for t in (kf, vf))
+    L, S = qf.shape[2], kf.shape[2]
+    x = qf @ kx.transpose(-1, -2) * qf.shape[-1] ** -0.5
+    if bias is not None:
+        x = x + bias.float()
+    hide = torch.zeros(L, S, dtype=torch.bool, device=q.device)
+    if causal:
+        hide = torch.arange(S, device=q.device)[None, :] > (torch.arange(L, device=q.device)[:, None] + (S - L))
+    if mask is not None:
+        hide = hide | ~mask
+    x = x.masked_fill(hide, float("-inf"))
+    m = x.amax(-1, keepdim=True).clamp_min(0.0) if n > 0 else x.amax(-1, keepdim=True)
+    m = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
+    e = torch.exp(x - m)
+    w = e / (n * torch.exp(-m) + e.sum(-1, keepdim=True)).clamp_min(1e-30)
+    o = w @ vx
+    o.backward(do.float())
+    return o, qf.grad, kf.grad, vf.grad
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FASN_FUZZ_GRIDS", "36"))))
+def test_randomized_large_causal_grids_write_every_block(pkg, dev, seed):
+    """Round 6 changed how causal launches hand their blocks to workgroups (pairs from 1 - 1.25 rounds, head groups, per-XCD orders): random LARGE grids
+    - 64 .. 192 heads, 5 .. 12 blocks, every head dim, plain / bias / dense mask / grouped K/V, L != S - with ALL of forward and gradients compared with a
+    torch fp32 reference computed on the device (tolerance of a 16-bit kernel against fp32: the point is that no block is missing or written twice;
+    FASN_FUZZ_GRIDS=N runs N seeds)."""
+    rng = np.random.default_rng(4200 + seed)
+    D = int(rng.choice([32, 64, 64, 128, 128, 256]))
+    B, H = int(rng.choice([2, 3, 4, 6])), int(rng.choice([16, 32]))
+    G = int(rng.choice([1, 1, 2, 4]))
+    L = int(rng.choice([640, 768, 1000, 1024, 1152, 1536]))
+    S = L if rng.integers(0, 3) else int(L + rng.choice([-128, 64, 200]))
+    kind = str(rng.choice(["plain", "plain", "bias_hls", "bias_b1ls", "dense"]))
+    dtype = [torch.float16, torch.bfloat16][int(rng.integers(0, 2))]
+    q = _rand((B, H, L, D), dtype, dev, 41).requires_grad_()
+    k, v = (_rand((B, H // G, S, D), dtype, dev, s_).requires_grad_() for s_ in (42, 43))
+    do = _rand((B, H, L, D), dtype, dev, 44, std=1.0)
+    gen = torch.Generator().manual_seed(seed)
+    mask = bias = None
+    if kind == "bias_hls":
+        bias = torch.randn(H, L, S, generator=gen).to(dtype).to(dev)
+    if kind == "bias_b1ls":
+        bias = torch.randn(B, 1, L, S, generator=gen).to(dtype).to(dev)
+    if kind == "dense":
+        mask = torch.rand(B, 1, L, S, generator=gen) < 0.8
+        mask[..., 0] = True
+        mask = mask.to(dev)
+    out = pkg.flash_attention_n(q, k, v, softmax_n_param=1.0, is_causal=True, attn_mask=mask, attn_bias=bias)
+    out.backward(do)
+    o, dq, dk, dv = _torch_reference_on_device(q, k, v, do, 1.0, True, mask, bias)
+    what = f"D{D} ({B},{H}/{H // G},{L},{S}) {kind} {dtype}"
+    for got, want, nm in ((out, o, "out"), (q.grad, dq, "dq"), (k.grad, dk, "dk"), (v.grad, dv, "dv")):
+        assert torch.isfinite(got).all(), f"{what} {nm}: non-finite"
+        err = (got.float() - want).abs().amax(dim=(-1, -2))          # per (batch, head)
+        lim = 0.02 * want.abs().amax(dim=(-1, -2)).clamp_min(0.05)
+        bad = (err > lim).nonzero()
+        assert bad.numel() == 0, f"{what} {nm}: (batch, head) {bad[:4].tolist()} off by {err.max().item():.3e}"
+
+
 @pytest.mark.parametrize("D", [128, 256])
 @pytest.mark.parametrize("B,H,Hkv,L,S", [(2, 16, 16, 640, 640), (2, 16, 16, 384, 640), (4, 8, 8, 650, 648), (2, 32, 8, 512, 512), (1, 8, 8, 1100, 1100)])
 def test_causal_two_wave_kernels_hand_blocks_out_by_head_groups(pkg, dev, B, H, Hkv, L, S, D):
